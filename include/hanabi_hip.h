@@ -1,0 +1,199 @@
+/*
+ * hanabi_hip.h — C-ABI of the MI355X-native Hanabi self-play hot path.
+ *
+ * One shared library (libhanabi_hip.so, built from hanabi-agents_amd/csrc/) exports
+ * exactly the entry points declared here. They are what a binding of the reference
+ * would call in place of
+ *   - the external C++ hanabi_learning_environment parallel env + canonical encoder
+ *     (reference call sites: hanabi_agents/rule_based/ruleset.py:4,
+ *      hanabi_agents/rule_based/rule_based.py:2,28,
+ *      hanabi_agents/rainbow/run_experiment.py:36,127-128,266-273,308), and
+ *   - the pybind11 sum_tree.SumTreef module
+ *     (sum_tree/sum_tree/src/sum_tree_py.cc:9-22, used by
+ *      hanabi_agents/rlax_dqn/priority_buffer.py:17,30-32,41-42,52).
+ *
+ * Conventions
+ *   - Every pointer argument named *_dev is a DEVICE pointer (HBM). Sizes are element
+ *     counts. No torch / C++ types cross this boundary.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). All work is
+ *     enqueued on it; no entry point synchronises unless its comment says so.
+ *   - Every function returns HB_OK (0) or a negative HB_ERR_* code and never throws;
+ *     hb_last_error() returns a thread-local message for the last failure.
+ *   - Handles are owned by the caller and are bound to the HIP device that was current
+ *     at creation. One handle per GPU; not re-entrant.
+ *   - There is NO CPU fallback: on a machine without a gfx950 device hb_env_create /
+ *     hb_tree_create fail with HB_ERR_NO_DEVICE.
+ */
+#ifndef HANABI_HIP_H
+#define HANABI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define HB_OK 0
+#define HB_ERR_INVALID (-1)   /* bad argument / unsupported configuration */
+#define HB_ERR_NO_DEVICE (-2) /* no HIP device, or kernel image not loadable */
+#define HB_ERR_HIP (-3)       /* a HIP runtime call failed */
+#define HB_ERR_ALIGN (-4)     /* an output pointer is not 16-byte aligned */
+#define HB_ERR_NOMEM (-5)
+
+const char* hb_last_error(void);
+int hb_abi_version(void);
+
+/* ---- game configuration ------------------------------------------------------------- */
+/* Mirrors the HanabiGame parameters the reference passes through rl_env.make
+ * (hanabi_agents/rainbow/run_experiment.py:119-128: 'Hanabi-Full', 'Hanabi-Small', ...).
+ * Limits: 2<=players<=5, 1<=colors<=5, 1<=ranks<=5, 1<=hand_size<=5,
+ * 1<=max_info<=15, 1<=max_life<=7, players*hand_size <= deck size. */
+typedef struct hb_config {
+  int32_t players;
+  int32_t colors;
+  int32_t ranks;
+  int32_t hand_size;
+  int32_t max_info;
+  int32_t max_life;
+  int32_t flags; /* HB_FLAG_* */
+} hb_config;
+
+#define HB_FLAG_AUTO_RESET 1u       /* a game that ends is re-dealt inside the same step */
+#define HB_FLAG_RESET_START_NEXT 2u /* auto-reset: new game starts with the seat after the one that just moved
+                                       (keeps N lock-stepped games on one acting seat); otherwise seat 0 */
+#define HB_FLAG_LENIENT_REWARD 4u   /* clamp negative rewards to 0 (run_experiment.py:41,310 LENIENT_SCORE) */
+
+/* step types, as dm_env / hanabi_agents/rlax_dqn/rlax_rainbow.py:292-308 use them */
+#define HB_STEP_FIRST 0
+#define HB_STEP_MID 1
+#define HB_STEP_LAST 2
+
+/* Derived sizes (pure host functions, usable without a GPU). */
+int hb_config_validate(const hb_config* cfg);
+int hb_num_actions(const hb_config* cfg);   /* 2*hand + (P-1)*(colors+ranks): 20 / 48 / 11 */
+int hb_obs_len(const hb_config* cfg);       /* canonical encoding length: 658 / 1280 / 171 */
+int hb_deck_size(const hb_config* cfg);     /* 50 / 20 */
+int hb_state_words(const hb_config* cfg);   /* u32 words per game-state row: 32 (P<=3) or 48 */
+
+/* ---- vectorised environment ----------------------------------------------------------
+ * N independent games. Game state lives in HBM as one row of hb_state_words() u32 per
+ * game (layout documented in DESIGN.md §3 and mirrored by oracle/hanabi_oracle.c).
+ *
+ * Replaces (external HLE, spec in SURVEY.md App. A): HanabiState::ApplyMove + deal +
+ * terminal test + reward, HanabiState::MoveIsLegal over all uids, and
+ * CanonicalObservationEncoder::Encode, fused into one kernel launch per step.          */
+typedef struct hb_env hb_env;
+
+/* first_game_id: global id of local game 0 (rank * n_games when sharding over GPUs);
+ * decks of game g, episode e are a pure function of (seed, first_game_id + g, e).      */
+int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t first_game_id, hb_env** out);
+int hb_env_destroy(hb_env* env);
+int64_t hb_env_num_games(const hb_env* env);
+
+/* Explicit-deck mode (parity / known-answer tests): decks_dev is [n_games, deck_size]
+ * uint8 card indices (color*ranks+rank); decks_dev[g][0] is the first card dealt. Each
+ * (re)deal of game g then uses that order instead of the Philox shuffle. NULL turns it
+ * off. The buffer is borrowed and must outlive its use.                                */
+int hb_env_set_decks(hb_env* env, const uint8_t* decks_dev);
+
+/* (Re)deal games. mask_dev: [n_games] uint8, nonzero = reset this game, NULL = all.
+ * start_player: seat that moves first (0..P-1). Clears the per-seat bookkeeping of the
+ * games it resets and bumps their episode counter.                                     */
+int hb_env_reset(hb_env* env, const uint8_t* mask_dev, int32_t start_player, void* stream);
+
+/* Encode the current observation + legal-move mask of the seat to act, without changing
+ * any state. obs_dev [n, obs_len] int8 0/1, legal_dev [n, n_actions] int8 0/1 (both
+ * 16-byte aligned); agent_reward_dev [n] float / agent_step_type_dev [n] int8 may be
+ * NULL.                                                                                */
+int hb_env_observe(hb_env* env, int8_t* obs_dev, int8_t* legal_dev, float* agent_reward_dev,
+                   int8_t* agent_step_type_dev, void* stream);
+
+/* One move per game: actions_dev[g] is the move uid (App. A.2 order: discard, play,
+ * reveal colour, reveal rank) chosen by game g's current seat. Then, for the seat that
+ * acts next (after an auto-reset: the first seat of the fresh game):
+ *   obs_dev / legal_dev          its canonical observation and legal mask   (required)
+ *   reward_dev     [n] float     score delta of THIS move                   (nullable)
+ *   terminal_dev   [n] int8      1 iff this move ended the game             (nullable)
+ *   agent_reward_dev [n] float   rewards accumulated for that seat since its own last
+ *                                move, frozen at the end of its episode     (nullable)
+ *   agent_step_type_dev [n] int8 HB_STEP_FIRST (seat has no move pending), HB_STEP_LAST
+ *                                (its episode ended since its last move), else MID
+ *   score_dev      [n] int8      terminal: final score of the finished game (0 if all
+ *                                lives lost); otherwise the running score   (nullable)
+ * An illegal uid leaves the game untouched, re-emits its observation and increments the
+ * counter read by hb_env_illegal_count().                                              */
+int hb_env_step(hb_env* env, const int32_t* actions_dev, int8_t* obs_dev, int8_t* legal_dev,
+                float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev,
+                int8_t* agent_step_type_dev, int8_t* score_dev, void* stream);
+
+/* Number of illegal uids seen since creation (synchronises the stream).                */
+int hb_env_illegal_count(hb_env* env, int64_t* out);
+
+/* Raw state rows for differential tests: rows_dev is [n_games, hb_state_words()] u32.  */
+int hb_env_export_state(hb_env* env, uint32_t* rows_dev, void* stream);
+int hb_env_import_state(hb_env* env, const uint32_t* rows_dev, void* stream);
+
+/* Uniform-random legal policy used by bench/tests (Philox(seed, game, draw)):
+ * actions_dev[g] = the k-th set entry of legal_dev[g], k uniform. No legal move -> 0.  */
+int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_actions, uint64_t seed,
+                            uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
+
+/* Tuning knob for measurements: games handled per 64-lane wavefront (16, 32 or 64).    */
+int hb_env_set_games_per_wave(hb_env* env, int32_t g);
+
+/* ---- GPU-resident sum tree ------------------------------------------------------------
+ * Replaces sum_tree.SumTreef (sum_tree/sum_tree/include/sum_tree.h:22-130 through
+ * sum_tree/sum_tree/src/sum_tree_py.cc:9-22). Flat fp32 heap array in HBM: node 1 is the
+ * root, leaves are nodes [cap, 2*cap); every internal node is exactly fl(left + right). */
+typedef struct hb_tree hb_tree;
+
+int hb_tree_create(int64_t capacity, hb_tree** out); /* capacity rounds up to a power of two (sum_tree.h:28) */
+int hb_tree_destroy(hb_tree* t);
+int64_t hb_tree_capacity(const hb_tree* t);          /* get_capacity() */
+/* device pointer to the 2*cap floats of the heap (tests / zero-copy consumers) */
+float* hb_tree_nodes(hb_tree* t);
+
+/* update_values(indices, values) (sum_tree.h:38-44). Duplicate indices inside one call:
+ * the LAST occurrence wins (the sequential order of the reference loop). n<=0 is a no-op.
+ * Out-of-range indices are ignored and counted in hb_tree_error_count().                */
+int hb_tree_update(hb_tree* t, const int64_t* idx_dev, const float* val_dev, int64_t n, void* stream);
+
+/* Ring insert used by PriorityBuffer.add_transitions (priority_buffer.py:29-32): leaves
+ * (start + i) mod cap for i in [0, n) take *value_dev (a device scalar, so the running
+ * max priority never visits the host).                                                  */
+int hb_tree_fill_range(hb_tree* t, int64_t start, int64_t n, const float* value_dev, void* stream);
+
+/* get_indices + get_values (sum_tree.h:46-72): for each quantile q in [0,1]:
+ * descend from the root with query = q * total, going left iff query < left (strict),
+ * else query -= left and right (sum_tree.h:92-105). idx_dev[i] = leaf index,
+ * val_dev[i] = its value (nullable).                                                    */
+int hb_tree_sample(hb_tree* t, const float* quantile_dev, int64_t* idx_dev, float* val_dev, int64_t n,
+                   void* stream);
+
+/* get_values(indices) (sum_tree.h:65-72). Out-of-range -> 0 and counted as an error.    */
+int hb_tree_get(hb_tree* t, const int64_t* idx_dev, float* val_dev, int64_t n, void* stream);
+
+/* get_total_val() into a device scalar.                                                 */
+int hb_tree_total(hb_tree* t, float* total_dev, void* stream);
+
+int hb_tree_error_count(hb_tree* t, int64_t* out); /* synchronises the stream */
+
+/* ---- fused prioritized-replay helpers (priority_buffer.py:36-52) ----------------------
+ * hb_per_sample: keys_i = float(linspace(1/B, 1, B)_i - u_i) with u_i in [0, 1/B) given
+ * as doubles (priority_buffer.py:37-40), tree descent, and
+ * prob_i = (leaf_i + 1e-10) / total in double (priority_buffer.py:42).                  */
+int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int64_t* idx_dev, double* prob_dev,
+                  void* stream);
+/* hb_per_update: p_i = (|td_i| + 1e-10)^alpha (double pow, rounded to float as the
+ * pybind float conversion does), max/min priority tracked in device scalars
+ * (priority_buffer.py:48-52), then hb_tree_update.                                      */
+int hb_per_update(hb_tree* t, const int64_t* idx_dev, const float* td_dev, int64_t n, double alpha,
+                  float* max_prio_dev, float* min_prio_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANABI_HIP_H */
