@@ -1,0 +1,271 @@
+// env_api.hip — host side of the C-ABI for the vectorised Hanabi env (include/hanabi_hip.h).
+// Owns the HBM state rows, validates arguments, picks the compiled kernel variant and
+// enqueues ONE kernel per call on the caller's stream. No CPU fallback exists: without a
+// device every constructor fails with HB_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/hanabi_hip.h"
+#include "common.hpp"
+#include "env_kernel.hpp"
+
+namespace hb {
+const EnvVariant* variants_full(int* n);
+const EnvVariant* variants_small(int* n);
+const EnvVariant* variants_vsmall(int* n);
+
+thread_local std::string g_error;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+static const EnvVariant* find_variant(const hb_config* c) {
+  const EnvVariant* (*tables[])(int*) = {variants_full, variants_small, variants_vsmall};
+  for (auto get : tables) {
+    int n = 0;
+    const EnvVariant* v = get(&n);
+    for (int i = 0; i < n; ++i)
+      if (v[i].P == c->players && v[i].C == c->colors && v[i].R == c->ranks && v[i].H == c->hand_size &&
+          v[i].INFO == c->max_info && v[i].LIFE == c->max_life)
+        return &v[i];
+  }
+  return nullptr;
+}
+
+// pure-host size formulas, valid for any configuration in range
+static int copies_of(const hb_config* c, int r) { return r == 0 ? 3 : (r == c->ranks - 1 ? 1 : 2); }
+static int deck_of(const hb_config* c) {
+  int per = 0;
+  for (int r = 0; r < c->ranks; ++r) per += copies_of(c, r);
+  return per * c->colors;
+}
+}  // namespace hb
+
+struct hb_env {
+  hb_config cfg;
+  const hb::EnvVariant* var;
+  long long n;
+  unsigned long long seed;
+  long long first_gid;
+  uint32_t* state;
+  unsigned long long* illegal;
+  const uint8_t* decks;
+  int gpw;
+  int device;
+};
+
+using hb::fail;
+
+extern "C" {
+
+const char* hb_last_error(void) { return hb::g_error.c_str(); }
+int hb_abi_version(void) { return HB_ABI_VERSION; }
+
+int hb_config_validate(const hb_config* c) {
+  if (!c) return fail(HB_ERR_INVALID, "null config");
+  if (c->players < 2 || c->players > 5) return fail(HB_ERR_INVALID, "players must be 2..5 (got %d)", c->players);
+  if (c->colors < 1 || c->colors > 5) return fail(HB_ERR_INVALID, "colors must be 1..5 (got %d)", c->colors);
+  if (c->ranks < 1 || c->ranks > 5) return fail(HB_ERR_INVALID, "ranks must be 1..5 (got %d)", c->ranks);
+  if (c->hand_size < 1 || c->hand_size > 5) return fail(HB_ERR_INVALID, "hand_size must be 1..5 (got %d)", c->hand_size);
+  if (c->max_info < 1 || c->max_info > 15) return fail(HB_ERR_INVALID, "max_info must be 1..15");
+  if (c->max_life < 1 || c->max_life > 7) return fail(HB_ERR_INVALID, "max_life must be 1..7");
+  if (c->players * c->hand_size > hb::deck_of(c)) return fail(HB_ERR_INVALID, "deck too small for the hands");
+  return HB_OK;
+}
+int hb_num_actions(const hb_config* c) { return 2 * c->hand_size + (c->players - 1) * (c->colors + c->ranks); }
+int hb_deck_size(const hb_config* c) { return hb::deck_of(c); }
+int hb_obs_len(const hb_config* c) {
+  const int bits = c->colors * c->ranks, P = c->players, H = c->hand_size, D = hb::deck_of(c);
+  return (P - 1) * H * bits + P + (D - P * H + bits + c->max_info + c->max_life) + D +
+         (P + 4 + P + c->colors + c->ranks + H + H + bits + 2) + P * H * (bits + c->colors + c->ranks);
+}
+int hb_state_words(const hb_config* c) { return c->players <= 3 ? 32 : 48; }
+
+int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t first_game_id, hb_env** out) {
+  if (!out) return fail(HB_ERR_INVALID, "null out");
+  *out = nullptr;
+  if (int rc = hb_config_validate(cfg)) return rc;
+  if (n_games <= 0) return fail(HB_ERR_INVALID, "n_games must be positive");
+  const hb::EnvVariant* var = hb::find_variant(cfg);
+  if (!var)
+    return fail(HB_ERR_INVALID,
+                "no compiled kernel for players=%d colors=%d ranks=%d hand=%d info=%d life=%d "
+                "(built: Hanabi-Full / -Small / -Very-Small, 2..5 players)",
+                cfg->players, cfg->colors, cfg->ranks, cfg->hand_size, cfg->max_info, cfg->max_life);
+  if (var->obs_len != hb_obs_len(cfg) || var->n_actions != hb_num_actions(cfg) || var->deck != hb_deck_size(cfg))
+    return fail(HB_ERR_INVALID, "internal: kernel sizes disagree with host formulas");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HB_ERR_NO_DEVICE, "no HIP device available");
+  hb_env* e = new (std::nothrow) hb_env();
+  if (!e) return fail(HB_ERR_NOMEM, "out of host memory");
+  e->cfg = *cfg;
+  e->var = var;
+  e->n = n_games;
+  e->seed = seed;
+  e->first_gid = first_game_id;
+  e->decks = nullptr;
+  e->gpw = 64;
+  HB_HIP_OR(hipGetDevice(&e->device), delete e);
+  const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->illegal), 8), { (void)hipFree(e->state); delete e; });
+  HB_HIP_OR(hipMemset(e->state, 0, bytes), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMemset(e->illegal, 0, 8), { hb_env_destroy(e); });
+  *out = e;
+  return HB_OK;
+}
+
+int hb_env_destroy(hb_env* e) {
+  if (!e) return HB_OK;
+  if (e->state) (void)hipFree(e->state);
+  if (e->illegal) (void)hipFree(e->illegal);
+  delete e;
+  return HB_OK;
+}
+
+int64_t hb_env_num_games(const hb_env* e) { return e ? e->n : 0; }
+
+int hb_env_set_decks(hb_env* e, const uint8_t* decks_dev) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  e->decks = decks_dev;
+  return HB_OK;
+}
+
+int hb_env_set_games_per_wave(hb_env* e, int32_t g) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (g != 16 && g != 32 && g != 64) return fail(HB_ERR_INVALID, "games per wave must be 16, 32 or 64");
+  e->gpw = g;
+  return HB_OK;
+}
+
+static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
+  a.state = e->state;
+  a.decks = e->decks;
+  a.illegal = e->illegal;
+  a.n = e->n;
+  a.seed = e->seed;
+  a.first_gid = e->first_gid;
+  a.flags = e->cfg.flags;
+  hb::LaunchFn fn = e->gpw == 16 ? e->var->g16 : (e->gpw == 32 ? e->var->g32 : e->var->g64);
+  fn(a, static_cast<hipStream_t>(stream));
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+static int check_out(const void* obs, const void* legal) {
+  if (!obs || !legal) return fail(HB_ERR_INVALID, "obs_dev and legal_dev are required");
+  if ((reinterpret_cast<uintptr_t>(obs) & 15) || (reinterpret_cast<uintptr_t>(legal) & 15))
+    return fail(HB_ERR_ALIGN, "obs_dev / legal_dev must be 16-byte aligned");
+  return HB_OK;
+}
+
+int hb_env_reset(hb_env* e, const uint8_t* mask_dev, int32_t start_player, void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (start_player < 0 || start_player >= e->cfg.players) return fail(HB_ERR_INVALID, "start_player out of range");
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_RESET;
+  a.mask = mask_dev;
+  a.start_player = start_player;
+  return launch(e, a, stream);
+}
+
+int hb_env_observe(hb_env* e, int8_t* obs_dev, int8_t* legal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev,
+                   void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (int rc = check_out(obs_dev, legal_dev)) return rc;
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_OBSERVE;
+  a.obs = obs_dev;
+  a.legal = legal_dev;
+  a.agent_reward = agent_reward_dev;
+  a.agent_step_type = agent_step_type_dev;
+  return launch(e, a, stream);
+}
+
+int hb_env_step(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* legal_dev, float* reward_dev,
+                int8_t* terminal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev, int8_t* score_dev,
+                void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (!actions_dev) return fail(HB_ERR_INVALID, "actions_dev is required");
+  if (int rc = check_out(obs_dev, legal_dev)) return rc;
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_STEP;
+  a.actions = actions_dev;
+  a.obs = obs_dev;
+  a.legal = legal_dev;
+  a.reward = reward_dev;
+  a.terminal = terminal_dev;
+  a.agent_reward = agent_reward_dev;
+  a.agent_step_type = agent_step_type_dev;
+  a.score = score_dev;
+  return launch(e, a, stream);
+}
+
+int hb_env_illegal_count(hb_env* e, int64_t* out) {
+  if (!e || !out) return fail(HB_ERR_INVALID, "null argument");
+  unsigned long long v = 0;
+  HB_HIP(hipMemcpy(&v, e->illegal, 8, hipMemcpyDeviceToHost));
+  *out = static_cast<int64_t>(v);
+  return HB_OK;
+}
+
+int hb_env_export_state(hb_env* e, uint32_t* rows_dev, void* stream) {
+  if (!e || !rows_dev) return fail(HB_ERR_INVALID, "null argument");
+  HB_HIP(hipMemcpyAsync(rows_dev, e->state, static_cast<size_t>(e->n) * e->var->state_words * 4, hipMemcpyDeviceToDevice,
+                        static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+int hb_env_import_state(hb_env* e, const uint32_t* rows_dev, void* stream) {
+  if (!e || !rows_dev) return fail(HB_ERR_INVALID, "null argument");
+  HB_HIP(hipMemcpyAsync(e->state, rows_dev, static_cast<size_t>(e->n) * e->var->state_words * 4, hipMemcpyDeviceToDevice,
+                        static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+
+// ---- uniform-random legal policy (bench / tests) ------------------------------------------
+__global__ void random_legal_kernel(const int8_t* __restrict__ legal, long long n, int n_actions, unsigned long long seed,
+                                    unsigned long long draw, long long first_gid, int32_t* __restrict__ actions) {
+  const long long g = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const unsigned long long gid = static_cast<unsigned long long>(first_gid + g);
+  uint32_t out[4];
+  hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),
+                    static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), out);
+  const int8_t* row = legal + g * n_actions;
+  unsigned long long m = 0;
+  for (int i = 0; i < n_actions; ++i) m |= static_cast<unsigned long long>(row[i] != 0) << i;
+  const int n_legal = __popcll(m);
+  int pick = 0;
+  if (n_legal > 0) {
+    int k = static_cast<int>(__umulhi(out[0], static_cast<uint32_t>(n_legal)));
+    while (k-- > 0) m &= m - 1;  // drop the k lowest set bits
+    pick = __ffsll(static_cast<long long>(m)) - 1;
+  }
+  actions[g] = pick;
+}
+
+int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_actions, uint64_t seed, uint64_t draw,
+                            int64_t first_game_id, int32_t* actions_dev, void* stream) {
+  if (!legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
+  if (n_games <= 0) return HB_OK;
+  const unsigned blocks = static_cast<unsigned>((n_games + 255) / 256);
+  hipLaunchKernelGGL(random_legal_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), legal_dev,
+                     static_cast<long long>(n_games), n_actions, static_cast<unsigned long long>(seed),
+                     static_cast<unsigned long long>(draw), static_cast<long long>(first_game_id), actions_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,603 @@
+// env_kernel.hpp — fused Hanabi env step + legal-move mask + canonical observation encoder
+// for gfx950 (MI355X). One kernel launch advances N independent games by one move.
+//
+// Replaces, for the reference's parallel-env call path (external hanabi_learning_environment;
+// spec SURVEY.md App. A; call sites hanabi_agents/rule_based/ruleset.py:4,
+// hanabi_agents/rainbow/run_experiment.py:266-273,308): HanabiState::ApplyMove + deal +
+// terminal test + reward (A.5), MoveIsLegal over all uids (A.4) and
+// CanonicalObservationEncoder::Encode (A.6).
+//
+// Mapping:
+//   * a 64-lane wavefront owns G consecutive games (G = 16/32/64); a 256-thread workgroup is
+//     four independent wavefronts. Game state is an AoS row of SW u32 (128 B or 192 B) in HBM;
+//     the wave copies its G rows HBM -> LDS with 16-byte coalesced loads (row stride SW+1 words
+//     so that lane-per-game LDS accesses are bank-conflict free).
+//   * lane g < G runs the rules for its game on the LDS row (scalar fields in VGPRs, hands /
+//     knowledge / deck addressed dynamically in LDS) and builds the observation as a BIT-PACKED
+//     vector (OBS_LEN bits = 21 words for 2 players) with compile-time field offsets.
+//   * a finished game is re-dealt by the whole wavefront: lane j draws the Philox key of deck
+//     position j, ranks it against the other keys with v_readlane broadcasts, and drops card j
+//     at its rank (sort-by-random-key shuffle; the tie-break by position makes it a deterministic function).
+//   * the wave then expands bits -> int8 cooperatively: every lane turns 16 bits into one
+//     16-byte store, so the [N, OBS_LEN] int8 output is written as full 1-KiB wave stores.
+// Everything is integer/bit work; the kernel is HBM-bound (943 B per env-step
+// for 2-player full Hanabi).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace hb {
+
+enum { MODE_STEP = 0, MODE_OBSERVE = 1, MODE_RESET = 2 };
+enum { MV_PLAY = 0, MV_DISCARD = 1, MV_RCOLOR = 2, MV_RRANK = 3 };
+
+struct EnvArgs {
+  uint32_t* state;
+  const int32_t* actions;
+  const uint8_t* mask;
+  const uint8_t* decks;
+  int8_t* obs;
+  int8_t* legal;
+  float* reward;
+  int8_t* terminal;
+  float* agent_reward;
+  int8_t* agent_step_type;
+  int8_t* score;
+  unsigned long long* illegal;
+  long long n;
+  unsigned long long seed;
+  long long first_gid;
+  int flags;
+  int mode;
+  int start_player;
+};
+
+// ---- compile-time description of one game configuration ----
+template <int P_, int C_, int R_, int H_, int INFO_, int LIFE_>
+struct Cfg {
+  static constexpr int P = P_, C = C_, R = R_, H = H_, INFO = INFO_, LIFE = LIFE_;
+  static constexpr int BITS = C * R;
+  static constexpr int copies(int r) { return r == 0 ? 3 : (r == R - 1 ? 1 : 2); }
+  static constexpr int cum(int r) {
+    int s = 0;
+    for (int i = 0; i < r; ++i) s += copies(i);
+    return s;
+  }
+  static constexpr int CPC = cum(R);  // cards per colour
+  static constexpr int D = C * CPC;   // deck size
+  static constexpr int A = 2 * H + (P - 1) * (C + R);
+  // observation sections
+  static constexpr int FLAGS_OFF = (P - 1) * H * BITS;
+  static constexpr int BOARD_OFF = FLAGS_OFF + P;
+  static constexpr int DECK_T = D - P * H;
+  static constexpr int FW_OFF = BOARD_OFF + DECK_T;
+  static constexpr int INFO_OFF = FW_OFF + BITS;
+  static constexpr int LIFE_OFF = INFO_OFF + INFO;
+  static constexpr int DISC_OFF = LIFE_OFF + LIFE;
+  static constexpr int LA_OFF = DISC_OFF + D;
+  static constexpr int LA_LEN = P + 4 + P + C + R + H + H + BITS + 2;
+  static constexpr int KN_OFF = LA_OFF + LA_LEN;
+  static constexpr int KN_SLOT = BITS + C + R;
+  static constexpr int OBS_LEN = KN_OFF + P * H * KN_SLOT;
+  static constexpr int NW = (OBS_LEN + 31) / 32;
+  static constexpr int NWP = (NW + 1) | 1;  // >= NW+1 zero pad word, odd LDS row stride
+  static constexpr int LW = 3;              // legal bits: 2 words + zero pad
+  // state row
+  static constexpr int SW = P <= 3 ? 32 : 48;
+  static constexpr int SWP = SW + 1;
+  static constexpr int W_HANDS = 10, W_KNOW = 10 + P, W_DECK = 10 + 3 * P;
+  static constexpr uint32_t ALL_PLAUSIBLE = ((1u << C) - 1u) | (((1u << R) - 1u) << 5);
+  static_assert(W_DECK * 4 + D <= SW * 4, "state row too small");
+  static_assert(BITS <= 25 && D <= 50 && A <= 64 && H <= 5 && P <= 5 && INFO <= 15 && LIFE <= 7, "limits");
+};
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// bit-packed observation under construction; every offset is a compile-time constant so the
+// words stay in VGPRs
+template <int NW>
+struct BitAcc {
+  uint32_t w[NW];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = 0;
+  }
+  template <int OFF, int LEN>
+  __device__ __forceinline__ void put(uint32_t v) {  // v < 2^LEN, LEN <= 32
+    static_assert(LEN >= 0 && LEN <= 32 && OFF >= 0 && (OFF + LEN + 31) / 32 <= NW, "put range");
+    if constexpr (LEN > 0) {  // (a zero-length section exists: 5-player very-small has no deck thermometer)
+      constexpr int wi = OFF >> 5, sh = OFF & 31;
+      w[wi] |= v << sh;
+      if constexpr (sh + LEN > 32) w[wi + 1] |= v >> (32 - sh);
+    }
+  }
+  template <int OFF, int LEN>
+  __device__ __forceinline__ void put64(uint64_t v) {  // v < 2^LEN, LEN <= 64
+    static_assert(LEN >= 0 && LEN <= 64, "put64 range");
+    if constexpr (LEN <= 32) {
+      put<OFF, LEN>(static_cast<uint32_t>(v));
+    } else {
+      put<OFF, 32>(static_cast<uint32_t>(v));
+      put<OFF + 32, LEN - 32>(static_cast<uint32_t>(v >> 32));
+    }
+  }
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 4 bits -> 4 bytes of 0/1 (bit i lands in byte i)
+__device__ __forceinline__ uint32_t spread4(uint32_t b) { return ((b & 15u) * 0x00204081u) & 0x01010101u; }
+
+// bits [k, k+16) of a packed row (the row has a zero word after its last data word)
+__device__ __forceinline__ uint32_t fetch16(const uint32_t* rowbits, int k) {
+  const int w = k >> 5;
+  const uint64_t v = (static_cast<uint64_t>(rowbits[w + 1]) << 32) | rowbits[w];
+  return static_cast<uint32_t>(v >> (k & 31)) & 0xFFFFu;
+}
+
+// wave-cooperative expansion of nvalid packed rows of L bits into nvalid*L int8 0/1 at `out`
+// (16-byte aligned): one 16-byte store per lane per 16 bits.
+template <int L>
+__device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride, int nvalid, int8_t* out, int lane) {
+  const int total = nvalid * L;
+  const int full = total >> 4;
+  uint4* out4 = reinterpret_cast<uint4*>(out);
+  for (int c = lane; c < full; c += 64) {
+    const int b0 = c << 4;
+    const int g = b0 / L;
+    const int k0 = b0 - g * L;
+    uint32_t v = fetch16(bits + g * row_stride, k0);
+    const int rem = L - k0;
+    if (rem < 16) v = (v & ((1u << rem) - 1u)) | ((fetch16(bits + (g + 1) * row_stride, 0) << rem) & 0xFFFFu);
+    uint4 o;
+    o.x = spread4(v);
+    o.y = spread4(v >> 4);
+    o.z = spread4(v >> 8);
+    o.w = spread4(v >> 12);
+    out4[c] = o;
+  }
+  for (int b = (full << 4) + lane; b < total; b += 64) {  // ragged tail of the last partial wave only
+    const int g = b / L, k = b - g * L;
+    out[b] = static_cast<int8_t>((bits[g * row_stride + (k >> 5)] >> (k & 31)) & 1u);
+  }
+}
+
+template <class K, int G>
+__global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
+  constexpr int P = K::P, C = K::C, R = K::R, H = K::H;
+  constexpr int PER_WAVE = G * (K::SWP + K::NWP + K::LW);
+  __shared__ uint32_t lds[4 * PER_WAVE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* const srow = lds + wave * PER_WAVE;
+  uint32_t* const obits = srow + G * K::SWP;
+  uint32_t* const lbits = obits + G * K::NWP;
+  const long long g0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * G;
+  const long long left = a.n - g0;
+  const int nvalid = left <= 0 ? 0 : (left < G ? static_cast<int>(left) : G);
+  const int mode = a.mode;
+
+  // ---- phase 1: state rows HBM -> LDS (coalesced 16-byte loads) ---------------------------
+  {
+    constexpr int Q = K::SW / 4;
+    const uint4* src = reinterpret_cast<const uint4*>(a.state + g0 * K::SW);
+    for (int e = lane; e < nvalid * Q; e += 64) {
+      const uint4 v = src[e];
+      const int g = e / Q, q = e - g * Q;
+      uint32_t* d = srow + g * K::SWP + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2a: rules, one lane per game ---------------------------------------------------
+  const bool active = lane < nvalid && lane < G;
+  const long long gi = g0 + lane;
+  uint32_t* const row = srow + lane * K::SWP;
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w6 = 0;
+  uint64_t accw = 0, disc = 0;
+  float out_reward = 0.f;
+  int out_term = 0, out_score = 0;
+  bool illegal = false, need_reset = false, keep_seats = true;
+  int reset_start = 0;
+
+  auto hand_n = [&](int p) -> int { return (w1 >> (15 + 3 * p)) & 7; };
+  auto fw = [&](int c) -> int { return (w1 >> (3 * c)) & 7; };
+  auto score_now = [&]() -> int {
+    if (((w0 >> 10) & 7) == 0) return 0;
+    int s = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += fw(c);
+    return s;
+  };
+
+  if (active) {
+    w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3]; w6 = row[6];
+    accw = (static_cast<uint64_t>(row[5]) << 32) | row[4];
+    disc = (static_cast<uint64_t>(row[9]) << 32) | row[8];
+    if (mode == MODE_RESET) {
+      need_reset = a.mask ? a.mask[gi] != 0 : true;
+      keep_seats = false;
+      reset_start = a.start_player;
+    } else if (mode == MODE_STEP && ((w0 >> 19) & 3) == 0) {
+      int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7;
+      const int s = (w0 >> 13) & 7;
+      int turns = (w0 >> 16) & 7, moves = (w0 >> 21) & 255;
+      const int uid = a.actions[gi];
+      int type = MV_PLAY, ci = 0, toff = 0, hcol = 0, hrank = 0;
+      bool ok = uid >= 0 && uid < K::A;
+      if (uid < H) { type = MV_DISCARD; ci = uid; }
+      else if (uid < 2 * H) { type = MV_PLAY; ci = uid - H; }
+      else if (uid < 2 * H + (P - 1) * C) { const int x = uid - 2 * H; type = MV_RCOLOR; toff = 1 + x / C; hcol = x % C; }
+      else { const int x = uid - 2 * H - (P - 1) * C; type = MV_RRANK; toff = 1 + x / R; hrank = x % R; }
+      int n_s = hand_n(s);
+      uint32_t hs = row[K::W_HANDS + s];
+      int t = s + toff;
+      if (t >= P) t -= P;
+      uint32_t match = 0;
+      if (ok) {
+        if (type == MV_DISCARD) ok = info < K::INFO && ci < n_s;
+        else if (type == MV_PLAY) ok = ci < n_s;
+        else {
+          const uint32_t ht = row[K::W_HANDS + t];
+          const int n_t = hand_n(t);
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            const int card = (ht >> (5 * i)) & 31;
+            const bool m = type == MV_RCOLOR ? (card / R == hcol) : (card % R == hrank);
+            if (i < n_t && m) match |= 1u << i;
+          }
+          ok = info > 0 && match != 0;
+        }
+      }
+      if (!ok) {
+        illegal = true;
+      } else {
+        // per-seat bookkeeping: this seat now has an open transition
+        w3 = (w3 | (1u << s)) & ~(1u << (5 + s));
+        accw &= ~(0xFFull << (8 * s));
+        const int before = score_now();
+        if (deck_size == 0) --turns;
+        int la_color = 0, la_rank = 0, la_scored = 0, la_info = 0;
+        if (type == MV_DISCARD || type == MV_PLAY) {
+          const int card = (hs >> (5 * ci)) & 31;
+          la_color = card / R;
+          la_rank = card % R;
+          bool to_discard = true;
+          if (type == MV_DISCARD) {
+            la_info = info < K::INFO;
+            info += la_info;
+          } else if (fw(la_color) == la_rank) {
+            w1 += 1u << (3 * la_color);
+            la_scored = 1;
+            to_discard = false;
+            if (la_rank == R - 1) { la_info = info < K::INFO; info += la_info; }
+          } else {
+            --life;
+          }
+          if (to_discard) disc += 1ull << (2 * card);
+          // remove slot ci: cards and knowledge shift left, last slot becomes empty
+          const uint32_t lowm = (1u << (5 * ci)) - 1u;
+          hs = (hs & lowm) | ((hs >> (5 * (ci + 1))) << (5 * ci)) | (31u << 20);
+          uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * s + 1]) << 32) | row[K::W_KNOW + 2 * s];
+          const uint64_t klow = (1ull << (12 * ci)) - 1ull;
+          kn = (kn & klow) | ((kn >> (12 * (ci + 1))) << (12 * ci));
+          --n_s;
+          if (deck_size > 0) {  // replacement deal (A.5 step 6): only the mover's hand can be short
+            const uint8_t* deckb = reinterpret_cast<const uint8_t*>(row + K::W_DECK);
+            const uint32_t card_new = deckb[K::D - deck_size];
+            hs = (hs & ~(31u << (5 * n_s))) | (card_new << (5 * n_s));
+            kn |= static_cast<uint64_t>(K::ALL_PLAUSIBLE) << (12 * n_s);
+            ++n_s;
+            --deck_size;
+          }
+          row[K::W_HANDS + s] = hs;
+          row[K::W_KNOW + 2 * s] = static_cast<uint32_t>(kn);
+          row[K::W_KNOW + 2 * s + 1] = static_cast<uint32_t>(kn >> 32);
+          w1 = (w1 & ~(7u << (15 + 3 * s))) | (static_cast<uint32_t>(n_s) << (15 + 3 * s));
+        } else {
+          --info;
+          uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * t + 1]) << 32) | row[K::W_KNOW + 2 * t];
+          const int n_t = hand_n(t);
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            if (i < n_t) {
+              const bool m = (match >> i) & 1u;
+              uint64_t k = (kn >> (12 * i)) & 0xFFFull;
+              if (type == MV_RCOLOR) k = m ? ((k & ~0x1Full) | (1ull << hcol) | (1ull << 10)) : (k & ~(1ull << hcol));
+              else k = m ? ((k & ~(0x1Full << 5)) | (1ull << (5 + hrank)) | (1ull << 11)) : (k & ~(1ull << (5 + hrank)));
+              kn = (kn & ~(0xFFFull << (12 * i))) | (k << (12 * i));
+            }
+          }
+          row[K::W_KNOW + 2 * t] = static_cast<uint32_t>(kn);
+          row[K::W_KNOW + 2 * t + 1] = static_cast<uint32_t>(kn >> 32);
+          if (type == MV_RCOLOR) la_color = hcol; else la_rank = hrank;
+        }
+        w2 = 1u | (static_cast<uint32_t>(s) << 1) | (static_cast<uint32_t>(type) << 4) | (static_cast<uint32_t>(ci) << 6) |
+             (static_cast<uint32_t>(toff) << 9) | (static_cast<uint32_t>(la_color) << 12) |
+             (static_cast<uint32_t>(la_rank) << 15) | (static_cast<uint32_t>(la_scored) << 18) |
+             (static_cast<uint32_t>(la_info) << 19) | (match << 20);
+        ++moves;
+        int cur = s + 1;
+        if (cur >= P) cur = 0;
+        w0 = static_cast<uint32_t>(deck_size) | (static_cast<uint32_t>(info) << 6) | (static_cast<uint32_t>(life) << 10) |
+             (static_cast<uint32_t>(cur) << 13) | (static_cast<uint32_t>(turns & 7) << 16) |
+             (static_cast<uint32_t>(moves & 255) << 21);
+        const int after = score_now();
+        int status = 0;
+        if (life < 1) status = 1;
+        else if (after >= C * R) status = 2;
+        else if (turns <= 0) status = 3;
+        w0 |= static_cast<uint32_t>(status) << 19;
+        int r = after - before;
+        if ((a.flags & 4) && r < 0) r = 0;
+        out_reward = static_cast<float>(r);
+        out_term = status != 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          if (((w3 >> q) & 1u) && !((w3 >> (5 + q)) & 1u)) {
+            const int8_t v = static_cast<int8_t>(static_cast<int8_t>(accw >> (8 * q)) + r);
+            accw = (accw & ~(0xFFull << (8 * q))) | (static_cast<uint64_t>(static_cast<uint8_t>(v)) << (8 * q));
+            if (out_term) w3 |= 1u << (5 + q);
+          }
+        }
+        if (out_term && (a.flags & 1)) {
+          need_reset = true;
+          reset_start = (a.flags & 2) ? cur : 0;
+        }
+      }
+    }
+    out_score = score_now();
+  }
+
+  // ---- phase 2b: wave-cooperative re-deal of finished / masked games -----------------------
+  {
+    unsigned long long todo = __ballot(need_reset);
+    while (todo) {
+      const int src = __ffsll(static_cast<long long>(todo)) - 1;
+      todo &= todo - 1;
+      uint8_t* deckb = reinterpret_cast<uint8_t*>(srow + src * K::SWP + K::W_DECK);
+      const unsigned long long gid = static_cast<unsigned long long>(a.first_gid + g0 + src);
+      if (a.decks) {
+        if (lane < K::D) deckb[lane] = a.decks[(g0 + src) * K::D + lane];
+      } else {
+        const uint32_t episode = __shfl(w6, src);
+        uint32_t out[4];
+        philox4x32_10(static_cast<uint32_t>(lane), episode, static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                      static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), out);
+        const uint32_t key = out[0];
+        int rank = 0;
+        for (int i = 0; i < K::D; ++i) {
+          const uint32_t ki = __shfl(key, i);
+          rank += (ki < key || (ki == key && i < lane)) ? 1 : 0;
+        }
+        if (lane < K::D) {
+          const int col = lane / K::CPC, k = lane - col * K::CPC;
+          const int rk = k < 3 ? 0 : 1 + (k - 3) / 2;
+          deckb[rank] = static_cast<uint8_t>(col * R + rk);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2c: deal fresh games, encode, publish fields -----------------------------------
+  if (active) {
+    if (need_reset) {
+      const uint8_t* deckb = reinterpret_cast<const uint8_t*>(row + K::W_DECK);
+      w0 = static_cast<uint32_t>(K::D - P * H) | (static_cast<uint32_t>(K::INFO) << 6) | (static_cast<uint32_t>(K::LIFE) << 10) |
+           (static_cast<uint32_t>(reset_start) << 13) | (static_cast<uint32_t>(P) << 16);
+      w1 = 0;
+      w2 = 0;
+      if (!keep_seats) { w3 = 0; accw = 0; }
+      w6 += 1;
+      disc = 0;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        uint32_t hc = 0;
+        uint64_t kn = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          if (i < H) {
+            hc |= static_cast<uint32_t>(deckb[p * H + i]) << (5 * i);
+            kn |= static_cast<uint64_t>(K::ALL_PLAUSIBLE) << (12 * i);
+          } else {
+            hc |= 31u << (5 * i);
+          }
+        }
+        row[K::W_HANDS + p] = hc;
+        row[K::W_KNOW + 2 * p] = static_cast<uint32_t>(kn);
+        row[K::W_KNOW + 2 * p + 1] = static_cast<uint32_t>(kn >> 32);
+        w1 |= static_cast<uint32_t>(H) << (15 + 3 * p);
+      }
+    }
+    if (mode != MODE_OBSERVE) {
+      row[0] = w0; row[1] = w1; row[2] = w2; row[3] = w3;
+      row[4] = static_cast<uint32_t>(accw); row[5] = static_cast<uint32_t>(accw >> 32);
+      row[6] = w6; row[7] = 0;
+      row[8] = static_cast<uint32_t>(disc); row[9] = static_cast<uint32_t>(disc >> 32);
+    }
+
+    if (mode != MODE_RESET) {
+      const int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7, o = (w0 >> 13) & 7;
+      BitAcc<K::NW> acc;
+      acc.clear();
+      uint64_t legal = 0;
+      const int n_o = hand_n(o);
+      // 1. other players' hands + "hand is short" flags; hint legality falls out of the same pass
+      static_for<P>([&](auto REL) {
+        constexpr int rel = decltype(REL)::value;
+        int p = o + rel;
+        if (p >= P) p -= P;
+        const int n_p = hand_n(p);
+        acc.template put<K::FLAGS_OFF + rel, 1>(n_p < H ? 1u : 0u);
+        if constexpr (rel >= 1) {
+          const uint32_t hc = row[K::W_HANDS + p];
+          uint32_t cmask = 0, rmask = 0;
+          static_for<H>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int card = (hc >> (5 * i)) & 31;
+            const bool have = i < n_p;
+            acc.template put<((rel - 1) * H + i) * K::BITS, K::BITS>(have ? (1u << card) : 0u);
+            if (have) { cmask |= 1u << (card / R); rmask |= 1u << (card % R); }
+          });
+          if (info > 0) {
+            legal |= static_cast<uint64_t>(cmask) << (2 * H + (rel - 1) * C);
+            legal |= static_cast<uint64_t>(rmask) << (2 * H + (P - 1) * C + (rel - 1) * R);
+          }
+        }
+      });
+      const uint32_t own = (1u << n_o) - 1u;
+      if (info < K::INFO) legal |= own;
+      legal |= static_cast<uint64_t>(own) << H;
+      // 2. board
+      acc.template put64<K::BOARD_OFF, K::DECK_T>((1ull << deck_size) - 1ull);
+      static_for<C>([&](auto CI) {
+        constexpr int c = decltype(CI)::value;
+        acc.template put<K::FW_OFF + c * R, R>((1u << fw(c)) >> 1);
+      });
+      acc.template put<K::INFO_OFF, K::INFO>((1u << info) - 1u);
+      acc.template put<K::LIFE_OFF, K::LIFE>((1u << life) - 1u);
+      // 3. discards: one thermometer per card identity
+      static_for<C * R>([&](auto CR) {
+        constexpr int cr = decltype(CR)::value;
+        constexpr int c = cr / R, r = cr % R;
+        const uint32_t cnt = static_cast<uint32_t>(disc >> (2 * cr)) & 3u;
+        acc.template put<K::DISC_OFF + c * K::CPC + K::cum(r), K::copies(r)>((1u << cnt) - 1u);
+      });
+      // 4. most recent move, observer-relative
+      {
+        const uint32_t valid = w2 & 1u;
+        const int la_player = (w2 >> 1) & 7, la_type = (w2 >> 4) & 3, la_ci = (w2 >> 6) & 7, la_toff = (w2 >> 9) & 7;
+        const int la_color = (w2 >> 12) & 7, la_rank = (w2 >> 15) & 7;
+        const uint32_t la_scored = (w2 >> 18) & 1u, la_info = (w2 >> 19) & 1u, la_mask = (w2 >> 20) & 31u;
+        int actor = la_player - o;
+        if (actor < 0) actor += P;
+        int target = actor + la_toff;
+        if (target >= P) target -= P;
+        const uint32_t reveal = valid & static_cast<uint32_t>(la_type >= MV_RCOLOR);
+        const uint32_t cardmv = valid & static_cast<uint32_t>(la_type <= MV_DISCARD);
+        const uint32_t is_rc = valid & static_cast<uint32_t>(la_type == MV_RCOLOR);
+        const uint32_t is_rr = valid & static_cast<uint32_t>(la_type == MV_RRANK);
+        const uint32_t is_play = valid & static_cast<uint32_t>(la_type == MV_PLAY);
+        constexpr int o1 = K::LA_OFF, o2 = o1 + P, o3 = o2 + 4, o4 = o3 + P, o5 = o4 + C, o6 = o5 + R, o7 = o6 + H,
+                      o8 = o7 + H, o9 = o8 + K::BITS;
+        acc.template put<o1, P>(valid << actor);
+        acc.template put<o2, 4>(valid << la_type);
+        acc.template put<o3, P>(reveal << target);
+        acc.template put<o4, C>(is_rc << la_color);
+        acc.template put<o5, R>(is_rr << la_rank);
+        acc.template put<o6, H>(reveal ? la_mask : 0u);
+        acc.template put<o7, H>(cardmv << la_ci);
+        acc.template put<o8, K::BITS>(cardmv << (la_color * R + la_rank));
+        acc.template put<o9, 2>((is_play & la_scored) | ((is_play & la_info) << 1));
+      }
+      // 5. card knowledge, observer first
+      static_for<P>([&](auto REL) {
+        constexpr int rel = decltype(REL)::value;
+        int p = o + rel;
+        if (p >= P) p -= P;
+        const int n_p = hand_n(p);
+        const uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * p + 1]) << 32) | row[K::W_KNOW + 2 * p];
+        static_for<H>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          const uint32_t k = static_cast<uint32_t>(kn >> (12 * i)) & 0xFFFu;
+          const uint32_t cp = k & 31u, rp = (k >> 5) & 31u;
+          uint32_t spread = 0;  // colour c plausible -> bit c*R
+#pragma unroll
+          for (int c = 0; c < C; ++c) spread |= ((cp >> c) & 1u) << (c * R);
+          const uint32_t plaus = spread * rp;  // disjoint R-bit fields: no carries
+          const uint32_t ch = (k >> 10) & 1u, rh = (k >> 11) & 1u;
+          uint64_t v = plaus | (static_cast<uint64_t>(ch ? cp : 0u) << K::BITS) |
+                       (static_cast<uint64_t>(rh ? rp : 0u) << (K::BITS + C));
+          if (i >= n_p) v = 0;
+          acc.template put64<K::KN_OFF + (rel * H + i) * K::KN_SLOT, K::KN_SLOT>(v);
+        });
+      });
+      uint32_t* ob = obits + lane * K::NWP;
+#pragma unroll
+      for (int i = 0; i < K::NW; ++i) ob[i] = acc.w[i];
+#pragma unroll
+      for (int i = K::NW; i < K::NWP; ++i) ob[i] = 0;
+      uint32_t* lb = lbits + lane * K::LW;
+      lb[0] = static_cast<uint32_t>(legal);
+      lb[1] = static_cast<uint32_t>(legal >> 32);
+      lb[2] = 0;
+      // per-game scalars (coalesced: consecutive lanes, consecutive addresses)
+      const uint32_t pend = (w3 >> o) & 1u, tsin = (w3 >> (5 + o)) & 1u;
+      if (a.agent_reward) a.agent_reward[gi] = pend ? static_cast<float>(static_cast<int8_t>(accw >> (8 * o))) : 0.f;
+      if (a.agent_step_type) a.agent_step_type[gi] = static_cast<int8_t>(!pend ? 0 : (tsin ? 2 : 1));
+      if (mode == MODE_STEP) {
+        if (a.reward) a.reward[gi] = out_reward;
+        if (a.terminal) a.terminal[gi] = static_cast<int8_t>(out_term);
+        if (a.score) a.score[gi] = static_cast<int8_t>(out_score);
+      }
+    }
+  }
+  if (mode == MODE_STEP) {
+    const unsigned long long bad = __ballot(illegal);
+    if (bad && lane == 0) atomicAdd(a.illegal, static_cast<unsigned long long>(__popcll(bad)));
+  }
+  __syncthreads();
+
+  // ---- phase 3: LDS -> HBM, full-width coalesced stores -------------------------------------
+  if (mode != MODE_OBSERVE) {
+    constexpr int Q = K::SW / 4;
+    uint4* dst = reinterpret_cast<uint4*>(a.state + g0 * K::SW);
+    for (int e = lane; e < nvalid * Q; e += 64) {
+      const int g = e / Q, q = e - g * Q;
+      const uint32_t* s = srow + g * K::SWP + 4 * q;
+      uint4 v;
+      v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
+      dst[e] = v;
+    }
+  }
+  if (mode != MODE_RESET) {
+    expand_rows<K::OBS_LEN>(obits, K::NWP, nvalid, a.obs + g0 * K::OBS_LEN, lane);
+    expand_rows<K::A>(lbits, K::LW, nvalid, a.legal + g0 * K::A, lane);
+  }
+}
+
+template <class K, int G>
+void launch_env(const EnvArgs& a, hipStream_t stream) {
+  const long long per_block = 4LL * G;
+  const unsigned blocks = static_cast<unsigned>((a.n + per_block - 1) / per_block);
+  if (blocks == 0) return;
+  hipLaunchKernelGGL((env_kernel<K, G>), dim3(blocks), dim3(256), 0, stream, a);
+}
+
+using LaunchFn = void (*)(const EnvArgs&, hipStream_t);
+struct EnvVariant {
+  int P, C, R, H, INFO, LIFE;
+  int obs_len, n_actions, deck, state_words;
+  LaunchFn g16, g32, g64;
+};
+
+template <class K>
+constexpr EnvVariant make_variant() {
+  return EnvVariant{K::P, K::C, K::R, K::H, K::INFO, K::LIFE, K::OBS_LEN, K::A, K::D, K::SW,
+                    &launch_env<K, 16>, &launch_env<K, 32>, &launch_env<K, 64>};
+}
+
+}  // namespace hb

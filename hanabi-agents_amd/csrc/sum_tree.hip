@@ -1,0 +1,449 @@
+// sum_tree.hip — GPU-resident sum tree for prioritized replay on gfx950.
+//
+// Replaces sum_tree.SumTreef, the reference's only native component
+// (sum_tree/sum_tree/include/sum_tree.h:22-130, bound in sum_tree/sum_tree/src/sum_tree_py.cc:9-22;
+// callers hanabi_agents/rlax_dqn/priority_buffer.py:17,30-32,41-42,52).
+//
+// Layout: one flat fp32 heap in HBM, node 1 = root, children of n = 2n, 2n+1, leaves =
+// [cap, 2cap). cap = 2^19 -> 4 MiB, resident in one XCD's L2 / the Infinity Cache. Instead of
+// the reference's pointer-linked nodes with a mutex each and a running float difference per
+// ancestor (sum_tree.h:80-90), every internal node is always exactly fl(left + right), so the
+// result does not depend on update order.
+//
+// Kernels (all latency-bound: a handful of dependent L2 round trips):
+//   update_small   n <= 1024 (the learner's B=256 priority update): ONE workgroup de-duplicates
+//                  (last occurrence wins, the sequential order of sum_tree.h:38-44), writes the
+//                  leaves and re-sums their ancestors level by level. Optionally fuses
+//                  p = (|td|+1e-10)^alpha and the running max/min (priority_buffer.py:48-52).
+//   fill_chunks    ring insert of a contiguous (wrapping) leaf range at one value
+//                  (priority_buffer.py:29-32): each workgroup owns an aligned 1024-leaf subtree,
+//                  rewrites its leaves and rebuilds its 10 levels through LDS.
+//   rebuild_top    one workgroup re-sums the levels above the 1024-leaf subtrees.
+//   sample         one WAVEFRONT per query: each round the 63 left-children of a 6-level
+//                  subtree are fetched by 63 lanes in one load and the 6 binary decisions
+//                  (strict <, subtract-on-right: sum_tree.h:92-105) are replayed from registers
+//                  with v_readlane, so cap = 2^19 costs 4 dependent loads instead of 19.
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "../../include/hanabi_hip.h"
+#include "common.hpp"
+
+using hb::fail;
+
+struct hb_tree {
+  long long cap;
+  int depth;          // log2(cap)
+  int chunk;          // leaves per rebuild workgroup = min(cap, 1024)
+  float* nodes;       // 2*cap
+  unsigned* stamp;    // cap, lazily allocated (large updates with possible duplicates)
+  unsigned long long* errors;
+  float* scratch;     // large per_update: transformed priorities
+  long long scratch_n;
+};
+
+namespace {
+
+constexpr int SMALL_MAX = 1024;
+
+// ---------------------------------------------------------------------------------------------
+// update_small: <<<1, 1024>>>
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void update_small_kernel(float* __restrict__ nodes, long long cap, int depth,
+                                                           const int64_t* __restrict__ idx, const float* __restrict__ val,
+                                                           int n, int per_mode, double alpha, float* max_prio,
+                                                           float* min_prio, unsigned long long* errors) {
+  __shared__ long long s_idx[SMALL_MAX];
+  __shared__ float s_red[2][16];
+  const int i = threadIdx.x;
+  long long my = -1;
+  float v = 0.f;
+  if (i < n) {
+    my = idx[i];
+    v = val[i];
+    if (per_mode) {
+      // (priorities + 1e-10) ** alpha on float32 data (priority_buffer.py:49): float add, the power in
+      // double rounded once to float (numpy powf may differ from this by 1 ulp)
+      const float x = fabsf(v) + 1e-10f;
+      v = static_cast<float>(pow(static_cast<double>(x), alpha));
+    }
+    if (my < 0 || my >= cap) {
+      atomicAdd(errors, 1ull);
+      my = -1;
+    }
+  }
+  s_idx[i] = my;
+  if (per_mode) {  // running max / min over ALL transformed priorities (priority_buffer.py:50-51)
+    float mx = i < n ? v : -INFINITY, mn = i < n ? v : INFINITY;
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      mn = fminf(mn, __shfl_xor(mn, o));
+    }
+    if ((i & 63) == 0) { s_red[0][i >> 6] = mx; s_red[1][i >> 6] = mn; }
+  }
+  __syncthreads();
+  if (per_mode && i == 0) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) { mx = fmaxf(mx, s_red[0][w]); mn = fminf(mn, s_red[1][w]); }
+    if (max_prio && mx > *max_prio) *max_prio = mx;
+    if (min_prio && mn < *min_prio) *min_prio = mn;
+  }
+  // last occurrence of an index wins
+  bool winner = my >= 0;
+  if (winner)
+    for (int j = i + 1; j < n; ++j)
+      if (s_idx[j] == my) { winner = false; break; }
+  if (winner) nodes[cap + my] = v;
+  __syncthreads();
+  // re-sum the ancestors bottom-up; threads sharing an ancestor write the same value
+  long long node = my >= 0 ? (cap + my) : 0;
+  for (int d = 0; d < depth; ++d) {
+    node >>= 1;
+    if (my >= 0) nodes[node] = nodes[2 * node] + nodes[2 * node + 1];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk rebuild: workgroup b owns the aligned subtree of `chunk` leaves number chunk_id(b)
+// ---------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void chunk_kernel(float* __restrict__ nodes, long long cap, int chunk, int first_chunk,
+                                                    long long start, long long n, const float* __restrict__ value_dev) {
+  __shared__ float s[2048];  // heap of the subtree: s[1] root, leaves s[chunk .. 2chunk)
+  const long long nchunks = cap / chunk;
+  const long long c = (first_chunk + static_cast<long long>(blockIdx.x)) % nchunks;
+  const long long leaf0 = c * chunk;
+  float fillv = 0.f;
+  if (FILL) fillv = *value_dev;
+  for (int j = threadIdx.x; j < chunk; j += 256) {
+    const long long leaf = leaf0 + j;
+    float v;
+    if (FILL) {
+      long long rel = leaf - start;
+      if (rel < 0) rel += cap;
+      const bool in = rel < n;
+      v = in ? fillv : nodes[cap + leaf];
+      if (in) nodes[cap + leaf] = v;
+    } else {
+      v = nodes[cap + leaf];
+    }
+    s[chunk + j] = v;
+  }
+  __syncthreads();
+  // subtree root is global node (cap + leaf0) / chunk; local node m at level width w maps to global base + offset
+  for (int w = chunk >> 1; w >= 1; w >>= 1) {
+    for (int j = threadIdx.x; j < w; j += 256) {
+      const float v = s[2 * (w + j)] + s[2 * (w + j) + 1];
+      s[w + j] = v;
+      nodes[(cap + leaf0) / (chunk / w) + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// levels above the chunk roots: <<<1, 1024>>>, ntop = cap / chunk chunk roots living at nodes [ntop, 2 ntop)
+__global__ __launch_bounds__(1024) void rebuild_top_kernel(float* __restrict__ nodes, int ntop) {
+  extern __shared__ float s[];  // 2 * ntop
+  for (int j = threadIdx.x; j < ntop; j += blockDim.x) s[ntop + j] = nodes[ntop + j];
+  __syncthreads();
+  for (int w = ntop >> 1; w >= 1; w >>= 1) {
+    for (int j = threadIdx.x; j < w; j += blockDim.x) {
+      const float v = s[2 * (w + j)] + s[2 * (w + j) + 1];
+      s[w + j] = v;
+      nodes[w + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// large arbitrary updates: last-occurrence-wins through a stamp array
+__global__ void stamp_kernel(unsigned* __restrict__ stamp, long long cap, const int64_t* __restrict__ idx, long long n,
+                             unsigned long long* errors) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = idx[i];
+  if (k < 0 || k >= cap) { atomicAdd(errors, 1ull); return; }
+  atomicMax(&stamp[k], static_cast<unsigned>(i + 1));
+}
+__global__ void scatter_kernel(float* __restrict__ nodes, unsigned* __restrict__ stamp, long long cap,
+                               const int64_t* __restrict__ idx, const float* __restrict__ val, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = idx[i];
+  if (k < 0 || k >= cap) return;
+  if (stamp[k] == static_cast<unsigned>(i + 1)) {
+    nodes[cap + k] = val[i];
+    stamp[k] = 0;
+  }
+}
+__global__ void per_transform_kernel(const float* __restrict__ td, float* __restrict__ out, long long n, double alpha,
+                                     float* max_prio, float* min_prio) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float p = static_cast<float>(pow(static_cast<double>(fabsf(td[i]) + 1e-10f), alpha));
+  out[i] = p;
+  // p > 0, so the IEEE bit patterns order like the values
+  if (max_prio) atomicMax(reinterpret_cast<unsigned*>(max_prio), __float_as_uint(p));
+  if (min_prio) atomicMin(reinterpret_cast<unsigned*>(min_prio), __float_as_uint(p));
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample: one wavefront per query
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_descend(const float* __restrict__ nodes, long long cap, int depth, float query,
+                                                  int lane, float* leaf_val) {
+  long long node = 1;
+  int remaining = depth;
+  while (remaining > 0) {
+    const int k = remaining < 6 ? remaining : 6;
+    // lane t (1 <= t < 2^k) stands for the subtree node with heap index t (root = 1) and fetches the value
+    // of that node's LEFT child: exactly the operand of the comparison made at that node.
+    float left = 0.f;
+    if (lane >= 1 && lane < (1 << k)) {
+      const int d = 31 - __clz(lane);
+      const long long parent = (node << d) + (lane - (1 << d));
+      left = nodes[2 * parent];
+    }
+    int t = 1;  // wave-uniform: kept in SGPRs so the broadcast is a v_readlane, not a ds_bpermute
+    for (int s = 0; s < k; ++s) {
+      const float l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(left), __builtin_amdgcn_readfirstlane(t)));
+      if (query < l) {
+        t = 2 * t;
+      } else {
+        query -= l;
+        t = 2 * t + 1;
+      }
+    }
+    node = (node << k) + (t - (1 << k));
+    remaining -= k;
+  }
+  if (leaf_val) *leaf_val = nodes[node];
+  return node - cap;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ nodes, long long cap, int depth,
+                                                     const float* __restrict__ q, int64_t* __restrict__ idx,
+                                                     float* __restrict__ val, long long n) {
+  const int lane = threadIdx.x & 63;
+  const long long i = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[i] * nodes[1])));  // sum_tree.h:47
+  float leaf;
+  const long long k = wave_descend(nodes, cap, depth, query, lane, &leaf);
+  if (lane == 0) {
+    idx[i] = k;
+    if (val) val[i] = leaf;
+  }
+}
+
+__global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict__ nodes, long long cap, int depth,
+                                                         const double* __restrict__ u, long long batch,
+                                                         int64_t* __restrict__ idx, double* __restrict__ prob) {
+  const int lane = threadIdx.x & 63;
+  const long long i = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= batch) return;
+  // numpy.linspace(1/B, 1, B)[i] - u[i] in float64, then the float conversion pybind applies (priority_buffer.py:37-41)
+  const double start = 1.0 / static_cast<double>(batch);
+  const double step = batch > 1 ? (1.0 - start) / static_cast<double>(batch - 1) : 0.0;
+  const double lin = (batch > 1 && i == batch - 1) ? 1.0 : static_cast<double>(i) * step + start;
+  const float total = nodes[1];
+  const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(static_cast<float>(lin - u[i]) * total)));
+  float leaf;
+  const long long k = wave_descend(nodes, cap, depth, query, lane, &leaf);
+  if (lane == 0) {
+    idx[i] = k;
+    prob[i] = (static_cast<double>(leaf) + 1e-10) / static_cast<double>(total);  // priority_buffer.py:42
+  }
+}
+
+__global__ void get_kernel(const float* __restrict__ nodes, long long cap, const int64_t* __restrict__ idx,
+                           float* __restrict__ val, long long n, unsigned long long* errors) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = idx[i];
+  if (k < 0 || k >= cap) {
+    atomicAdd(errors, 1ull);
+    val[i] = 0.f;
+  } else {
+    val[i] = nodes[cap + k];
+  }
+}
+
+int rebuild(hb_tree* t, int first_chunk, int nchunks_touched, hipStream_t s) {
+  hipLaunchKernelGGL((chunk_kernel<false>), dim3(nchunks_touched), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
+                     first_chunk, 0LL, 0LL, static_cast<const float*>(nullptr));
+  const int ntop = static_cast<int>(t->cap / t->chunk);
+  if (ntop > 1)
+    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
+                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hb_tree_create(int64_t capacity, hb_tree** out) {
+  if (!out) return fail(HB_ERR_INVALID, "null out");
+  *out = nullptr;
+  if (capacity < 1 || capacity > (1LL << 23)) return fail(HB_ERR_INVALID, "capacity must be in [1, 2^23]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HB_ERR_NO_DEVICE, "no HIP device available");
+  long long cap = 1;
+  int depth = 0;
+  while (cap < capacity) { cap <<= 1; ++depth; }  // depth = ceil(log2(capacity)) (sum_tree.h:28)
+  hb_tree* t = new (std::nothrow) hb_tree();
+  if (!t) return fail(HB_ERR_NOMEM, "out of host memory");
+  t->cap = cap;
+  t->depth = depth;
+  t->chunk = cap < 1024 ? static_cast<int>(cap) : 1024;
+  t->stamp = nullptr;
+  t->scratch = nullptr;
+  t->scratch_n = 0;
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->nodes), 2 * cap * sizeof(float)), delete t);
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->errors), 8), { (void)hipFree(t->nodes); delete t; });
+  HB_HIP_OR(hipMemset(t->nodes, 0, 2 * cap * sizeof(float)), hb_tree_destroy(t));
+  HB_HIP_OR(hipMemset(t->errors, 0, 8), hb_tree_destroy(t));
+  *out = t;
+  return HB_OK;
+}
+
+int hb_tree_destroy(hb_tree* t) {
+  if (!t) return HB_OK;
+  if (t->nodes) (void)hipFree(t->nodes);
+  if (t->errors) (void)hipFree(t->errors);
+  if (t->stamp) (void)hipFree(t->stamp);
+  if (t->scratch) (void)hipFree(t->scratch);
+  delete t;
+  return HB_OK;
+}
+
+int64_t hb_tree_capacity(const hb_tree* t) { return t ? t->cap : 0; }
+float* hb_tree_nodes(hb_tree* t) { return t ? t->nodes : nullptr; }
+
+static int update_impl(hb_tree* t, const int64_t* idx, const float* val, int64_t n, int per_mode, double alpha,
+                       float* max_prio, float* min_prio, hipStream_t s) {
+  if (n <= 0) return HB_OK;
+  if (n <= SMALL_MAX) {
+    const int threads = n <= 256 ? 256 : (n <= 512 ? 512 : 1024);
+    hipLaunchKernelGGL(update_small_kernel, dim3(1), dim3(threads), 0, s, t->nodes, t->cap, t->depth, idx, val,
+                       static_cast<int>(n), per_mode, alpha, max_prio, min_prio, t->errors);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+  }
+  if (!t->stamp) {
+    HB_HIP(hipMalloc(reinterpret_cast<void**>(&t->stamp), t->cap * sizeof(unsigned)));
+    HB_HIP(hipMemsetAsync(t->stamp, 0, t->cap * sizeof(unsigned), s));
+  }
+  const float* v = val;
+  if (per_mode) {
+    if (t->scratch_n < n) {
+      if (t->scratch) HB_HIP(hipFree(t->scratch));
+      t->scratch = nullptr;
+      HB_HIP(hipMalloc(reinterpret_cast<void**>(&t->scratch), n * sizeof(float)));
+      t->scratch_n = n;
+    }
+    hipLaunchKernelGGL(per_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, val, t->scratch, n, alpha, max_prio,
+                       min_prio);
+    v = t->scratch;
+  }
+  const unsigned blocks = static_cast<unsigned>((n + 255) / 256);
+  hipLaunchKernelGGL(stamp_kernel, dim3(blocks), dim3(256), 0, s, t->stamp, t->cap, idx, n, t->errors);
+  hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, s, t->nodes, t->stamp, t->cap, idx, v, n);
+  return rebuild(t, 0, static_cast<int>(t->cap / t->chunk), s);
+}
+
+int hb_tree_update(hb_tree* t, const int64_t* idx_dev, const float* val_dev, int64_t n, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (n > 0 && (!idx_dev || !val_dev)) return fail(HB_ERR_INVALID, "null argument");
+  return update_impl(t, idx_dev, val_dev, n, 0, 0.0, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int hb_per_update(hb_tree* t, const int64_t* idx_dev, const float* td_dev, int64_t n, double alpha, float* max_prio_dev,
+                  float* min_prio_dev, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (n > 0 && (!idx_dev || !td_dev)) return fail(HB_ERR_INVALID, "null argument");
+  // array float32 ** python float: the exponent is taken at float32 precision (priority_buffer.py:49)
+  const double a = static_cast<double>(static_cast<float>(alpha));
+  return update_impl(t, idx_dev, td_dev, n, 1, a, max_prio_dev, min_prio_dev, static_cast<hipStream_t>(stream));
+}
+
+int hb_tree_fill_range(hb_tree* t, int64_t start, int64_t n, const float* value_dev, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (n <= 0) return HB_OK;
+  if (!value_dev) return fail(HB_ERR_INVALID, "null value_dev");
+  if (start < 0 || start >= t->cap) return fail(HB_ERR_INVALID, "start out of range");
+  if (n > t->cap) n = t->cap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long nchunks = t->cap / t->chunk;
+  long long touched = ((start % t->chunk) + n + t->chunk - 1) / t->chunk;
+  if (touched > nchunks) touched = nchunks;
+  hipLaunchKernelGGL((chunk_kernel<true>), dim3(static_cast<unsigned>(touched)), dim3(256), 0, s, t->nodes, t->cap,
+                     t->chunk, static_cast<int>(start / t->chunk), static_cast<long long>(start),
+                     static_cast<long long>(n), value_dev);
+  const int ntop = static_cast<int>(nchunks);
+  if (ntop > 1)
+    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
+                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_tree_sample(hb_tree* t, const float* quantile_dev, int64_t* idx_dev, float* val_dev, int64_t n, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (n <= 0) return HB_OK;
+  if (!quantile_dev || !idx_dev) return fail(HB_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(sample_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, quantile_dev, idx_dev, val_dev,
+                     static_cast<long long>(n));
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int64_t* idx_dev, double* prob_dev, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (batch <= 0) return HB_OK;
+  if (!u_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, u_dev, static_cast<long long>(batch),
+                     idx_dev, prob_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_tree_get(hb_tree* t, const int64_t* idx_dev, float* val_dev, int64_t n, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (n <= 0) return HB_OK;
+  if (!idx_dev || !val_dev) return fail(HB_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(get_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t->nodes, t->cap, idx_dev, val_dev, static_cast<long long>(n),
+                     t->errors);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_tree_total(hb_tree* t, float* total_dev, void* stream) {
+  if (!t || !total_dev) return fail(HB_ERR_INVALID, "null argument");
+  HB_HIP(hipMemcpyAsync(total_dev, t->nodes + 1, sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+
+int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream) {
+  if (!t || !nodes_dev) return fail(HB_ERR_INVALID, "null argument");
+  HB_HIP(hipMemcpyAsync(nodes_dev, t->nodes, 2 * t->cap * sizeof(float), hipMemcpyDeviceToDevice,
+                        static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+
+int hb_tree_error_count(hb_tree* t, int64_t* out) {
+  if (!t || !out) return fail(HB_ERR_INVALID, "null argument");
+  unsigned long long v = 0;
+  HB_HIP(hipMemcpy(&v, t->errors, 8, hipMemcpyDeviceToHost));
+  *out = static_cast<int64_t>(v);
+  return HB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""ctypes declarations for every symbol of include/hanabi_hip.h (the drop-in boundary)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLAG_AUTO_RESET, FLAG_RESET_START_NEXT, FLAG_LENIENT_REWARD = 1, 2, 4
+STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
+
+
+class HbError(RuntimeError):
+    pass
+
+
+class HbConfig(C.Structure):
+    """`hb_config` of include/hanabi_hip.h."""
+
+    _fields_ = [(n, C.c_int32) for n in ("players", "colors", "ranks", "hand_size", "max_info", "max_life", "flags")]
+
+    def __repr__(self):
+        return "HbConfig(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_) + ")"
+
+
+# HanabiGame parameter presets of rl_env.make (hanabi_agents/rainbow/run_experiment.py:119-128)
+GAME_TYPES = {
+    "Hanabi-Full": dict(colors=5, ranks=5, hand_size=lambda p: 5 if p < 4 else 4, max_info=8, max_life=3),
+    "Hanabi-Full-CardKnowledge": dict(colors=5, ranks=5, hand_size=lambda p: 5 if p < 4 else 4, max_info=8, max_life=3),
+    "Hanabi-Small": dict(colors=2, ranks=5, hand_size=lambda p: 2, max_info=3, max_life=1),
+    "Hanabi-Very-Small": dict(colors=1, ranks=5, hand_size=lambda p: 2, max_info=3, max_life=1),
+}
+
+
+def make_config(game="Hanabi-Full", players=2, flags=0):
+    g = GAME_TYPES[game]
+    return HbConfig(players, g["colors"], g["ranks"], g["hand_size"](players), g["max_info"], g["max_life"], flags)
+
+
+def library_path():
+    return os.path.join(_HERE, "libhanabi_hip.so")
+
+
+# name -> (restype, argtypes); one entry per symbol declared in include/hanabi_hip.h
+_P, _I32, _I64, _U64, _F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+_CFG = C.POINTER(HbConfig)
+SIGNATURES = {
+    "hb_last_error": (C.c_char_p, []),
+    "hb_abi_version": (C.c_int, []),
+    "hb_config_validate": (C.c_int, [_CFG]),
+    "hb_num_actions": (C.c_int, [_CFG]),
+    "hb_obs_len": (C.c_int, [_CFG]),
+    "hb_deck_size": (C.c_int, [_CFG]),
+    "hb_state_words": (C.c_int, [_CFG]),
+    "hb_env_create": (C.c_int, [_CFG, _I64, _U64, _I64, C.POINTER(_P)]),
+    "hb_env_destroy": (C.c_int, [_P]),
+    "hb_env_num_games": (_I64, [_P]),
+    "hb_env_set_decks": (C.c_int, [_P, _P]),
+    "hb_env_reset": (C.c_int, [_P, _P, _I32, _P]),
+    "hb_env_observe": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hb_env_step": (C.c_int, [_P] + [_P] * 8 + [_P]),
+    "hb_env_illegal_count": (C.c_int, [_P, C.POINTER(_I64)]),
+    "hb_env_export_state": (C.c_int, [_P, _P, _P]),
+    "hb_env_import_state": (C.c_int, [_P, _P, _P]),
+    "hb_random_legal_actions": (C.c_int, [_P, _I64, _I32, _U64, _U64, _I64, _P, _P]),
+    "hb_env_set_games_per_wave": (C.c_int, [_P, _I32]),
+    "hb_tree_create": (C.c_int, [_I64, C.POINTER(_P)]),
+    "hb_tree_destroy": (C.c_int, [_P]),
+    "hb_tree_capacity": (_I64, [_P]),
+    "hb_tree_nodes": (_P, [_P]),
+    "hb_tree_export_nodes": (C.c_int, [_P, _P, _P]),
+    "hb_tree_update": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "hb_tree_fill_range": (C.c_int, [_P, _I64, _I64, _P, _P]),
+    "hb_tree_sample": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "hb_tree_get": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "hb_tree_total": (C.c_int, [_P, _P, _P]),
+    "hb_tree_error_count": (C.c_int, [_P, C.POINTER(_I64)]),
+    "hb_per_sample": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "hb_per_update": (C.c_int, [_P, _P, _P, _I64, _F64, _P, _P, _P]),
+}
+
+
+def lib():
+    """Load libhanabi_hip.so (built by __graft_entry__.build() / csrc/Makefile). Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise HbError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(there is no CPU fallback)")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise HbError(f"hanabi_hip error {rc}: {lib().hb_last_error().decode()}")
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

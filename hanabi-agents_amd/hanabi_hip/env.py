@@ -1,0 +1,126 @@
+"""HanabiEnv — N lock-stepped Hanabi games resident on one MI355X.
+
+Host-side mirror of the parallel environment the reference's agents are driven with (the external
+`hanabi_learning_environment` parallel env): `reset()`, `step(actions)` and
+batched `(observation [N, obs_len], legal_moves [N, n_actions])` int8 tensors, which is exactly
+what `DQNAgent.explore/add_experience` consume as `observations[1]`
+(hanabi_agents/rlax_dqn/rlax_rainbow.py:284-308). All buffers are torch CUDA tensors owned by
+this object and rewritten in place by every step (zero host traffic).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi as K
+
+
+class HanabiEnv:
+    def __init__(self, game="Hanabi-Full", players=2, n_games=1, seed=1234, first_game_id=0, auto_reset=True,
+                 lockstep=True, lenient_reward=False, device=None, config=None, decks=None, start_player=0,
+                 games_per_wave=None):
+        if not torch.cuda.is_available():
+            raise K.HbError("HanabiEnv needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+        self.L = K.lib()
+        flags = ((K.FLAG_AUTO_RESET if auto_reset else 0) | (K.FLAG_RESET_START_NEXT if lockstep else 0) |
+                 (K.FLAG_LENIENT_REWARD if lenient_reward else 0))
+        self.cfg = config if config is not None else K.make_config(game, players, flags)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.n = int(n_games)
+        self.players = self.cfg.players
+        self.num_actions = self.L.hb_num_actions(C.byref(self.cfg))
+        self.obs_len = self.L.hb_obs_len(C.byref(self.cfg))
+        self.deck_size = self.L.hb_deck_size(C.byref(self.cfg))
+        self.state_words = self.L.hb_state_words(C.byref(self.cfg))
+        self.first_game_id = int(first_game_id)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            K.check(self.L.hb_env_create(C.byref(self.cfg), self.n, seed, first_game_id, C.byref(h)))
+        self.h = h
+        dev = self.device
+        self.obs = torch.zeros((self.n, self.obs_len), dtype=torch.int8, device=dev)
+        self.legal = torch.zeros((self.n, self.num_actions), dtype=torch.int8, device=dev)
+        self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.terminal = torch.zeros(self.n, dtype=torch.int8, device=dev)
+        self.agent_reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.agent_step_type = torch.zeros(self.n, dtype=torch.int8, device=dev)
+        self.score = torch.zeros(self.n, dtype=torch.int8, device=dev)
+        self._decks = None
+        if games_per_wave is not None:
+            self.set_games_per_wave(games_per_wave)
+        if decks is not None:
+            self.set_decks(decks)
+        self.reset(start_player=start_player)
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            self.L.hb_env_destroy(h)
+            self.h = None
+
+    # -- configuration -----------------------------------------------------------------------
+    def set_games_per_wave(self, g):
+        K.check(self.L.hb_env_set_games_per_wave(self.h, int(g)))
+
+    def set_decks(self, decks):
+        """Explicit decks [N, deck_size] uint8 (first card dealt first), or None for Philox shuffles."""
+        if decks is None:
+            self._decks = None
+            K.check(self.L.hb_env_set_decks(self.h, None))
+            return
+        d = torch.as_tensor(decks, dtype=torch.uint8).reshape(self.n, self.deck_size).contiguous().to(self.device)
+        self._decks = d  # keep the borrowed buffer alive
+        K.check(self.L.hb_env_set_decks(self.h, K.dptr(d)))
+
+    # -- stepping ----------------------------------------------------------------------------
+    def reset(self, mask=None, start_player=0):
+        """(Re)deal all games, or those with mask != 0, and refresh obs/legal for the seat to act."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            assert m.shape == (self.n,)
+        K.check(self.L.hb_env_reset(self.h, K.dptr(m), int(start_player), K.current_stream()))
+        return self.observe()
+
+    def observe(self):
+        K.check(self.L.hb_env_observe(self.h, K.dptr(self.obs), K.dptr(self.legal), K.dptr(self.agent_reward),
+                                      K.dptr(self.agent_step_type), K.current_stream()))
+        return self.obs, self.legal
+
+    def step(self, actions):
+        """actions: int32 CUDA tensor [N] of move uids. Returns (obs, legal, reward, terminal) views."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()):
+            a = torch.as_tensor(a).to(device=self.device, dtype=torch.int32).contiguous()
+        assert a.shape == (self.n,)
+        K.check(self.L.hb_env_step(self.h, K.dptr(a), K.dptr(self.obs), K.dptr(self.legal), K.dptr(self.reward),
+                                   K.dptr(self.terminal), K.dptr(self.agent_reward), K.dptr(self.agent_step_type),
+                                   K.dptr(self.score), K.current_stream()))
+        return self.obs, self.legal, self.reward, self.terminal
+
+    def random_legal_actions(self, seed, draw, out=None):
+        """Uniform-random legal move per game (bench / tests policy)."""
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        K.check(self.L.hb_random_legal_actions(K.dptr(self.legal), self.n, self.num_actions, seed, draw,
+                                               self.first_game_id, K.dptr(out), K.current_stream()))
+        return out
+
+    # -- introspection -------------------------------------------------------------------------
+    def illegal_count(self):
+        v = C.c_int64()
+        K.check(self.L.hb_env_illegal_count(self.h, C.byref(v)))
+        return v.value
+
+    def export_state(self):
+        rows = torch.empty((self.n, self.state_words), dtype=torch.int32, device=self.device)
+        K.check(self.L.hb_env_export_state(self.h, K.dptr(rows), K.current_stream()))
+        return rows
+
+    def import_state(self, rows):
+        r = torch.as_tensor(rows).to(device=self.device, dtype=torch.int32).contiguous()
+        assert r.shape == (self.n, self.state_words)
+        K.check(self.L.hb_env_import_state(self.h, K.dptr(r), K.current_stream()))
+
+    def current_player(self):
+        """Seat to act in every game (equal across games in lock-step mode)."""
+        return (self.export_state()[:, 0] >> 13) & 7

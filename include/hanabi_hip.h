@@ -153,8 +153,10 @@ typedef struct hb_tree hb_tree;
 int hb_tree_create(int64_t capacity, hb_tree** out); /* capacity rounds up to a power of two (sum_tree.h:28) */
 int hb_tree_destroy(hb_tree* t);
 int64_t hb_tree_capacity(const hb_tree* t);          /* get_capacity() */
-/* device pointer to the 2*cap floats of the heap (tests / zero-copy consumers) */
+/* device pointer to the 2*cap floats of the heap (zero-copy consumers) */
 float* hb_tree_nodes(hb_tree* t);
+/* copy of the whole heap into nodes_dev[2*cap] (differential tests) */
+int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream);
 
 /* update_values(indices, values) (sum_tree.h:38-44). Duplicate indices inside one call:
  * the LAST occurrence wins (the sequential order of the reference loop). n<=0 is a no-op.

@@ -1,0 +1,172 @@
+"""GPU parity: the fused HIP env/encoder kernel against the CPU oracle, bit for bit, through
+the C-ABI (hanabi_hip.HanabiEnv -> libhanabi_hip.so)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(game, players, n, seed=7, flags=O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT, decks=None, gpw=None,
+          first_game_id=0):
+    import hanabi_hip
+
+    cfg = hanabi_hip.make_config(game, players, flags)
+    env = hanabi_hip.HanabiEnv(config=cfg, n_games=n, seed=seed, first_game_id=first_game_id, decks=decks,
+                               games_per_wave=gpw)
+    orc = O.OracleEnv(O.make_config(game, players, flags), n, seed=seed, first_game_id=first_game_id, decks=decks)
+    return env, orc
+
+
+def _assert_same(env, orc, out, what):
+    import torch
+
+    torch.cuda.synchronize()
+    for name, t in (("obs", env.obs), ("legal", env.legal), ("agent_reward", env.agent_reward),
+                    ("agent_step_type", env.agent_step_type)):
+        got = t.cpu().numpy()
+        assert np.array_equal(got, out[name]), f"{what}: {name} differs in {np.argwhere(got != out[name])[:5]}"
+    if "reward" in out:
+        for name, t in (("reward", env.reward), ("terminal", env.terminal), ("score", env.score)):
+            assert np.array_equal(t.cpu().numpy(), out[name]), f"{what}: {name} differs"
+    st = env.export_state().cpu().numpy().view(np.uint32)
+    assert np.array_equal(st, orc.export_state()), f"{what}: state rows differ"
+
+
+@pytest.mark.parametrize("game,players,n,gpw", [
+    ("Hanabi-Full", 2, 1000, 64), ("Hanabi-Full", 2, 777, 16), ("Hanabi-Full", 3, 300, 32),
+    ("Hanabi-Full", 4, 257, 64), ("Hanabi-Full", 5, 512, 64), ("Hanabi-Full", 5, 100, 16),
+    ("Hanabi-Small", 2, 500, 64), ("Hanabi-Small", 5, 130, 32), ("Hanabi-Very-Small", 2, 64, 64),
+    ("Hanabi-Very-Small", 5, 65, 16), ("Hanabi-Full", 2, 1, 64), ("Hanabi-Small", 3, 17, 64),
+])
+def test_random_self_play_bit_exact(game, players, n, gpw):
+    """Random-legal self-play with auto-reset: obs, legal, rewards, step types and the raw state
+    rows stay identical to the oracle for hundreds of moves (several episodes per game)."""
+    env, orc = _pair(game, players, n, gpw=gpw, first_game_id=12345)
+    _assert_same(env, orc, orc.observe(), "after reset")
+    steps = 150 if game == "Hanabi-Full" else 80
+    for t in range(steps):
+        act = env.random_legal_actions(seed=4321, draw=t)
+        a = act.cpu().numpy()
+        assert np.array_equal(a, O.random_legal_actions(orc.observe()["legal"], 4321, t, first_game_id=12345))
+        env.step(act)
+        _assert_same(env, orc, orc.step(a), f"step {t}")
+    assert env.illegal_count() == 0 == orc.illegal_count()
+
+
+def test_without_auto_reset_games_stay_terminal():
+    env, orc = _pair("Hanabi-Small", 2, 200, flags=0)
+    for t in range(60):
+        act = env.random_legal_actions(seed=5, draw=t)
+        env.step(act)
+        _assert_same(env, orc, orc.step(act.cpu().numpy()), f"step {t}")
+    status = (env.export_state().cpu().numpy().view(np.uint32)[:, 0] >> 19) & 3
+    assert (status != 0).all()
+    # explicit masked reset of half of them
+    mask = (np.arange(200) % 2).astype(np.uint8)
+    env.reset(mask=mask, start_player=1)
+    orc.reset(mask=mask, start_player=1)
+    _assert_same(env, orc, orc.observe(), "masked reset")
+
+
+def test_illegal_and_out_of_range_actions():
+    import torch
+
+    env, orc = _pair("Hanabi-Full", 2, 128)
+    bad = np.zeros(128, np.int32)          # discard at 8 info tokens: illegal
+    bad[::3] = 99
+    bad[1::3] = -5
+    env.step(torch.as_tensor(bad).cuda())
+    _assert_same(env, orc, orc.step(bad), "illegal step")
+    assert env.illegal_count() == 128 == orc.illegal_count()
+
+
+def test_explicit_decks_scripted_game():
+    """Same hand-worked scenario as tests/test_oracle_env.py::test_scripted_full_game_prefix."""
+    cfg = O.make_config()
+    deck = []
+    for c in range(5):
+        for r in range(5):
+            deck += [c * 5 + r] * (3 if r == 0 else (1 if r == 4 else 2))
+    decks = np.tile(np.array(deck, np.uint8), (4, 1))
+    env, orc = _pair("Hanabi-Full", 2, 4, flags=0, decks=decks)
+    for uid in (5, 10, 8, 9, 5, 8):
+        act = np.full(4, uid, np.int32)
+        env.step(act)
+        _assert_same(env, orc, orc.step(act), f"uid {uid}")
+    assert env.terminal.cpu().numpy().tolist() == [1] * 4 and env.reward.cpu().numpy().tolist() == [-2.0] * 4
+
+
+def test_full_size_properties_32768_games():
+    """BASELINE config (2p full, 32 768 games): size-independent properties on the GPU output
+    alone, plus a sampled comparison against the oracle on a slice of the games."""
+    import hanabi_hip
+    import torch
+
+    n = 32768
+    flags = O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=1234)
+    sl = slice(20000, 20256)
+    orc = O.OracleEnv(O.make_config("Hanabi-Full", 2, flags), 256, seed=1234, first_game_id=20000)
+    copies = np.array([3, 2, 2, 2, 1] * 5)
+    total_terminals = 0
+    for t in range(200):
+        act = env.random_legal_actions(seed=4321, draw=t)
+        env.step(act)
+        out = orc.step(act[sl].cpu().numpy())
+        if t % 20 == 0 or t == 199:
+            obs = env.obs.cpu().numpy()
+            assert set(np.unique(obs)) <= {0, 1}
+            assert np.array_equal(obs[sl], out["obs"]) and np.array_equal(env.legal[sl].cpu().numpy(), out["legal"])
+            # one-hot / thermometer structure
+            hands = obs[:, 0:125].reshape(n, 5, 25)
+            assert (hands.sum(2) <= 1).all()
+            deck = obs[:, 127:167]
+            assert (np.diff(deck.astype(np.int8), axis=1) <= 0).all()          # thermometer is monotone
+            fw = obs[:, 167:192].reshape(n, 5, 5)
+            assert (fw.sum(2) <= 1).all()
+            disc = obs[:, 203:253]
+            assert (disc.sum(1) + (fw.argmax(2) + fw.max(2)).sum(1) <= 50).all()
+            st = env.export_state().cpu().numpy().view(np.uint32)
+            info, life = (st[:, 0] >> 6) & 15, (st[:, 0] >> 10) & 7
+            assert (obs[:, 192:200].sum(1) == info).all() and (obs[:, 200:203].sum(1) == life).all()
+            assert (((st[:, 0] >> 13) & 7) == (t + 1) % 2).all()               # lock-step seat
+            # card conservation from the raw state rows
+            dsz = st[:, 0] & 63
+            cnt = np.zeros((n, 25), np.int64)
+            d64 = st[:, 8].astype(np.uint64) | (st[:, 9].astype(np.uint64) << np.uint64(32))
+            for i in range(25):
+                cnt[:, i] += ((d64 >> np.uint64(2 * i)) & np.uint64(3)).astype(np.int64)
+            for c in range(5):
+                f = (st[:, 1] >> (3 * c)) & 7
+                for r in range(5):
+                    cnt[:, c * 5 + r] += (f > r)
+            for p in range(2):
+                hn = (st[:, 1] >> (15 + 3 * p)) & 7
+                for i in range(5):
+                    card = (st[:, 10 + p] >> (5 * i)) & 31
+                    ok = i < hn
+                    np.add.at(cnt, (np.flatnonzero(ok), card[ok]), 1)
+            deckb = st[:, 16:29].copy().view(np.uint8).reshape(n, 52)[:, :50]
+            for pos in range(50):
+                ok = pos >= 50 - dsz
+                np.add.at(cnt, (np.flatnonzero(ok), deckb[ok, pos]), 1)
+            assert (cnt == copies[None]).all()
+        total_terminals += int(env.terminal.sum().item())
+    assert total_terminals > n  # every game finished at least once on average
+    assert env.illegal_count() == 0
+    torch.cuda.synchronize()
+
+
+def test_unaligned_output_is_rejected():
+    import ctypes as C
+
+    import hanabi_hip
+    import torch
+    from hanabi_hip import _capi as K
+
+    env = hanabi_hip.HanabiEnv(n_games=8)
+    buf = torch.zeros(8 * 658 + 64, dtype=torch.int8, device="cuda")
+    rc = K.lib().hb_env_observe(env.h, C.c_void_p(buf.data_ptr() + 1), K.dptr(env.legal), None, None, K.current_stream())
+    assert rc == -4 and b"aligned" in K.lib().hb_last_error()

@@ -1,0 +1,169 @@
+"""GPU parity: the HIP sum tree / PER kernels against the oracle, the reference golden vectors
+(tests/golden/*.json, captured from the reference build) and the gtest known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def T(cap):
+    import hanabi_hip
+
+    return hanabi_hip.SumTree(cap)
+
+
+def dev(a, dt):
+    import torch
+
+    return torch.as_tensor(np.asarray(a, dtype=dt)).cuda()
+
+
+def test_gtest_known_answers():  # sum_tree/sum_tree/src/test_sum_tree.cc:45-117
+    assert T(7).get_capacity() == 8 and T(9).get_capacity() == 16
+    t = T(4)
+    t.update_value(0, 1.0)
+    assert t.get_value(0) == 1 and t.get_total_val() == 1
+    t.update_value(2, 2.0)
+    assert t.get_total_val() == 3
+    t.update_value(2, 1.0)
+    assert t.get_value(2) == 1 and t.get_total_val() == 2
+    t = T(4)
+    t.update_values([0, 1, 2, 3], [1.0, 2.0, 3.0, 4.0])
+    assert t.get_total_val() == 10 and t.get_values([0, 1, 2, 3]) == [1, 2, 3, 4]
+    assert t.get_indices([0.0, 0.099, 0.1, 0.299, 0.3, 0.599, 0.6, 1.0]) == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert "capacity=4" in repr(t)
+    with pytest.raises(IndexError):
+        t.get_value(17)
+
+
+def test_reference_golden_vectors():
+    gold = json.load(open(os.path.join(GOLD, "sumtree_ref.json")))
+    for case in gold["cases"]:
+        t = T(case["requested_capacity"])
+        assert t.get_capacity() == case["capacity"]
+        for op in case["ops"]:
+            t.update_values(op["update_idx"], op["update_val"])
+            assert t.get_total_val() == op["total"]
+            assert t.get_values(range(case["capacity"])) == op["leaves"]
+            idx, val = t.sample_dev(dev(op["quantiles"], np.float32))
+            assert idx.cpu().tolist() == op["sample_idx"]
+            assert np.array_equal(val.cpu().numpy(), np.array(op["sample_val"], np.float32))
+    t8 = T(8)
+    t8.update_values([0, 1, 2, 3], [0.6] * 4)
+    assert t8.get_index(1.0) == 7
+
+
+@pytest.mark.parametrize("cap", [1, 2, 64, 1024, 4096, 2 ** 19])
+def test_random_ops_match_oracle_bit_exact(cap):
+    rng = np.random.default_rng(cap)
+    t, o = T(cap), O.OracleTree(cap)
+    for rnd in range(6):
+        n = int(rng.integers(1, min(cap, 3000) + 1))
+        if rnd % 2:
+            n = min(n, 256)                                   # the learner-sized single-workgroup path
+        idx = rng.integers(0, cap, n)                         # duplicates allowed: last one wins
+        val = rng.random(n).astype(np.float32) * 3            # arbitrary floats: internal sums must round alike
+        t.update_dev(dev(idx, np.int64), dev(val, np.float32))
+        o.update(idx, val)
+        assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:]), f"round {rnd}"
+        q = np.concatenate([rng.random(300), [0.0, 1.0]]).astype(np.float32)
+        gi, gv = t.sample_dev(dev(q, np.float32))
+        oi, ov = o.sample(q)
+        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov)
+    assert t.error_count() == 0
+
+
+def test_out_of_range_indices_are_ignored_and_counted():
+    t, o = T(16), O.OracleTree(16)
+    idx, val = [3, 99, -1, 3, 5], [1.0, 2.0, 3.0, 4.0, 5.0]
+    t.update_values(idx, val)
+    o.update(idx, val)
+    assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:])
+    assert t.error_count() == 2
+    assert t.get_values([5, 100]) == [5.0, 0.0]
+
+
+@pytest.mark.parametrize("cap,start,n", [(8, 6, 4), (2 ** 19, 2 ** 19 - 100, 32768), (2 ** 19, 0, 32768),
+                                         (4096, 1000, 4096), (1024, 1023, 2), (512, 10, 100)])
+def test_fill_range_matches_oracle(cap, start, n):
+    import torch
+
+    rng = np.random.default_rng(1)
+    t, o = T(cap), O.OracleTree(cap)
+    idx = rng.permutation(cap)[: cap // 2]
+    val = rng.random(len(idx)).astype(np.float32)
+    for a in range(0, len(idx), 1000):
+        t.update_dev(dev(idx[a:a + 1000], np.int64), dev(val[a:a + 1000], np.float32))
+    o.update(idx, val)
+    v = torch.tensor([0.6], dtype=torch.float32, device="cuda")
+    t.fill_range_dev(start, n, v)
+    o.fill_range(start, n, np.float32(0.6))
+    assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:])
+
+
+def test_per_sample_and_update_match_oracle_and_reference_golden():
+    import torch
+
+    gold = json.load(open(os.path.join(GOLD, "replay_ref.json")))
+    for case in gold["priority"]:
+        cap = case["capacity"]
+        t, o = T(cap), O.OracleTree(cap)
+        mx = torch.tensor([case["max_priority0"]], dtype=torch.float32, device="cuda")
+        mn = mx.clone()
+        omx = omn = case["max_priority0"]
+        oldest = 0
+        for step in case["steps"]:
+            n = len(step["batch"]["act"])
+            t.fill_range_dev(oldest, n, mx)
+            o.fill_range(oldest, n, np.float32(omx))
+            oldest = (oldest + n) % cap
+            u = np.array(step["uniforms"], np.float64)
+            gi, gp = t.per_sample_dev(dev(u, np.float64))
+            oi, op = o.per_sample(u)
+            assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gp.cpu().numpy(), op)   # vs oracle: exact
+            assert gi.cpu().tolist() == step["sample_indices"]                                       # vs reference
+            assert np.allclose(gp.cpu().numpy(), step["sample_prios"], rtol=1e-6, atol=0)
+            td = np.array(step["tds"], np.float32)
+            t.per_update_dev(gi, dev(td, np.float32), case["alpha"], mx, mn)
+            omx, omn = o.per_update(oi, td, case["alpha"], omx, omn)
+            assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:])
+            assert float(mx.cpu()[0]) == np.float32(omx) and float(mn.cpu()[0]) == np.float32(omn)
+            ref = np.array(step["leaves_after_update"], np.float32)
+            assert np.allclose(t.nodes().cpu().numpy()[cap:], ref, rtol=2e-7, atol=0)  # numpy powf vs pow: 1 ulp
+            # resynchronise all three on the reference's exact leaves
+            t.update_dev(dev(np.arange(cap), np.int64), dev(ref[:cap], np.float32))
+            o.update(np.arange(cap), ref[:cap])
+            omx, omn = step["max_priority"], step["min_priority"]
+            mx.fill_(omx)
+            mn.fill_(omn)
+            omx, omn = float(np.float32(omx)), float(np.float32(omn))
+
+
+def test_learner_sized_per_cycle_at_full_capacity():
+    """cap 2^19, B=256: stratified sample -> update, 50 rounds, exact vs the oracle."""
+    rng = np.random.default_rng(3)
+    cap = 2 ** 19
+    t, o = T(cap), O.OracleTree(cap)
+    import torch
+
+    mx = torch.tensor([0.6], dtype=torch.float32, device="cuda")
+    mn = mx.clone()
+    omx = omn = float(np.float32(0.6))
+    t.fill_range_dev(0, 300000, mx)
+    o.fill_range(0, 300000, np.float32(0.6))
+    for _ in range(50):
+        u = rng.random(256) / 256
+        gi, gp = t.per_sample_dev(dev(u, np.float64))
+        oi, op = o.per_sample(u)
+        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gp.cpu().numpy(), op)
+        td = (rng.standard_normal(256) * 2).astype(np.float32)
+        t.per_update_dev(gi, dev(td, np.float32), 0.6, mx, mn)
+        omx, omn = o.per_update(oi, td, 0.6, omx, omn)
+    assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:])
+    assert float(mx.cpu()[0]) == np.float32(omx) and float(mn.cpu()[0]) == np.float32(omn)
