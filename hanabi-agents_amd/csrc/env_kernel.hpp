@@ -164,11 +164,23 @@ __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride
   uint4* out4 = reinterpret_cast<uint4*>(out);
   for (int c = lane; c < full; c += 64) {
     const int b0 = c << 4;
-    const int g = b0 / L;
-    const int k0 = b0 - g * L;
-    uint32_t v = fetch16(bits + g * row_stride, k0);
-    const int rem = L - k0;
-    if (rem < 16) v = (v & ((1u << rem) - 1u)) | ((fetch16(bits + (g + 1) * row_stride, 0) << rem) & 0xFFFFu);
+    int g = b0 / L;
+    int k = b0 - g * L;
+    // gather 16 consecutive bits of the row-major [nvalid, L] bit matrix; a chunk spans two rows when
+    // L is not a multiple of 16 and up to three when L < 16 (the 11-move legal mask of Hanabi-Small)
+    uint32_t v = 0;
+    int have = 0;
+#pragma unroll 1
+    while (have < 16) {
+      uint32_t piece = fetch16(bits + g * row_stride, k);
+      const int rem = L - k;
+      if (rem < 16) piece &= (1u << rem) - 1u;
+      v |= piece << have;
+      have += rem;
+      ++g;
+      k = 0;
+    }
+    v &= 0xFFFFu;
     uint4 o;
     o.x = spread4(v);
     o.y = spread4(v >> 4);
