@@ -212,6 +212,20 @@ int hb_env_step(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* 
   return launch(e, a, stream);
 }
 
+#ifdef HB_STAMPS
+// diagnostic library only: step once with per-wavefront phase stamps written to stamps_dev
+int hb_env_step_stamped(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* legal_dev,
+                        unsigned long long* stamps_dev, void* stream) {
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_STEP;
+  a.actions = actions_dev;
+  a.obs = obs_dev;
+  a.legal = legal_dev;
+  a.stamps = stamps_dev;
+  return launch(e, a, stream);
+}
+#endif
+
 int hb_env_illegal_count(hb_env* e, int64_t* out) {
   if (!e || !out) return fail(HB_ERR_INVALID, "null argument");
   unsigned long long v = 0;

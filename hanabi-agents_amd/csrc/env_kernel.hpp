@@ -51,7 +51,29 @@ struct EnvArgs {
   int flags;
   int mode;
   int start_player;
+  unsigned long long* stamps;  // diagnostic builds only (-DHB_STAMPS): 12 u64 per wavefront
 };
+
+// In-kernel phase stamps (cdna_hip_programming.md §7): compiled in only with -DHB_STAMPS, into a
+// separate diagnostic library; the shipped kernel contains none of this.
+#ifdef HB_STAMPS
+#define HB_STAMP(slot)                                                                               \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    unsigned long long hb_t_;                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    if (a.stamps && lane == 0) a.stamps[(static_cast<long long>(blockIdx.x) * 4 + wave) * 12 + (slot)] = hb_t_; \
+  } while (0)
+#define HB_STAMP_REAL(slot)                                                                          \
+  do {                                                                                               \
+    if (a.stamps && lane == 0)                                                                       \
+      a.stamps[(static_cast<long long>(blockIdx.x) * 4 + wave) * 12 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define HB_STAMP(slot) do { } while (0)
+#define HB_STAMP_REAL(slot) do { } while (0)
+#endif
 
 // ---- compile-time description of one game configuration ----
 template <int P_, int C_, int R_, int H_, int INFO_, int LIFE_>
@@ -148,50 +170,49 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // 4 bits -> 4 bytes of 0/1 (bit i lands in byte i)
 __device__ __forceinline__ uint32_t spread4(uint32_t b) { return ((b & 15u) * 0x00204081u) & 0x01010101u; }
 
-// bits [k, k+16) of a packed row (the row has a zero word after its last data word)
-__device__ __forceinline__ uint32_t fetch16(const uint32_t* rowbits, int k) {
-  const int w = k >> 5;
-  const uint64_t v = (static_cast<uint64_t>(rowbits[w + 1]) << 32) | rowbits[w];
-  return static_cast<uint32_t>(v >> (k & 31)) & 0xFFFFu;
-}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));  // lowers to one global_store_dwordx4 on gfx950
 
-// wave-cooperative expansion of nvalid packed rows of L bits into nvalid*L int8 0/1 at `out`
-// (16-byte aligned): one 16-byte store per lane per 16 bits.
+// Wave-cooperative expansion of nvalid bit-packed rows (L bits each, `row_stride` words apart in LDS)
+// into the row-major [nvalid, L] int8 0/1 matrix at `out`.
+// The chunk grid is [row][L/16]: lane -> (row g, chunk l) reads its 16 bits with ONE ds_read_u16 and
+// writes ONE 16-byte store at out + g*L + 16*l. Rows are L bytes apart, so the stores are only
+// byte-aligned, but a wave still covers contiguous spans of each row; no chunk ever straddles rows.
+// The L%16 trailing bytes of every row are written by a second, short pass.
 template <int L>
 __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride, int nvalid, int8_t* out, int lane) {
-  const int total = nvalid * L;
-  const int full = total >> 4;
-  uint4* out4 = reinterpret_cast<uint4*>(out);
-  for (int c = lane; c < full; c += 64) {
-    const int b0 = c << 4;
-    int g = b0 / L;
-    int k = b0 - g * L;
-    // gather 16 consecutive bits of the row-major [nvalid, L] bit matrix; a chunk spans two rows when
-    // L is not a multiple of 16 and up to three when L < 16 (the 11-move legal mask of Hanabi-Small)
-    uint32_t v = 0;
-    int have = 0;
-#pragma unroll 1
-    while (have < 16) {
-      uint32_t piece = fetch16(bits + g * row_stride, k);
-      const int rem = L - k;
-      if (rem < 16) piece &= (1u << rem) - 1u;
-      v |= piece << have;
-      have += rem;
-      ++g;
-      k = 0;
+  constexpr int CPR = L / 16, TAIL = L % 16;
+  if constexpr (CPR > 0) {
+    const int chunks = nvalid * CPR;
+#pragma unroll 2
+    for (int c = lane; c < chunks; c += 64) {
+      const int g = c / CPR, l = c - g * CPR;
+      const uint32_t v = reinterpret_cast<const uint16_t*>(bits + g * row_stride)[l];
+      u32x4 o;
+      o.x = spread4(v);
+      o.y = spread4(v >> 4);
+      o.z = spread4(v >> 8);
+      o.w = spread4(v >> 12);
+      *reinterpret_cast<u32x4_unaligned*>(out + g * L + 16 * l) = o;
     }
-    v &= 0xFFFFu;
-    uint4 o;
-    o.x = spread4(v);
-    o.y = spread4(v >> 4);
-    o.z = spread4(v >> 8);
-    o.w = spread4(v >> 12);
-    out4[c] = o;
   }
-  for (int b = (full << 4) + lane; b < total; b += 64) {  // ragged tail of the last partial wave only
-    const int g = b / L, k = b - g * L;
-    out[b] = static_cast<int8_t>((bits[g * row_stride + (k >> 5)] >> (k & 31)) & 1u);
+  if constexpr (TAIL > 0) {
+    const int n = nvalid * TAIL;
+    for (int e = lane; e < n; e += 64) {
+      const int g = e / TAIL, j = e - g * TAIL, k = CPR * 16 + j;
+      out[g * L + k] = static_cast<int8_t>((bits[g * row_stride + (k >> 5)] >> (k & 31)) & 1u);
+    }
   }
+}
+
+// Wavefronts of a workgroup never share data here, so phases are ordered with a WAVE-level
+// barrier only: LDS operations of one wavefront execute in issue order, the fences keep the
+// compiler from moving LDS accesses across the phase boundary, and no s_barrier couples a wave
+// to a slower neighbour (one that is re-dealing games).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <class K, int G>
@@ -209,6 +230,18 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   const long long left = a.n - g0;
   const int nvalid = left <= 0 ? 0 : (left < G ? static_cast<int>(left) : G);
   const int mode = a.mode;
+  HB_STAMP_REAL(10);
+  HB_STAMP(0);
+
+  // the per-game inputs are requested first so their HBM latency hides under the state copy
+  const bool active = lane < nvalid && lane < G;
+  const long long gi = g0 + lane;
+  int uid_in = 0;
+  bool mask_in = true;
+  if (active) {
+    if (mode == MODE_STEP) uid_in = a.actions[gi];
+    if (mode == MODE_RESET && a.mask) mask_in = a.mask[gi] != 0;
+  }
 
   // ---- phase 1: state rows HBM -> LDS (coalesced 16-byte loads) ---------------------------
   {
@@ -221,11 +254,11 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
-  __syncthreads();
+  HB_STAMP(1);
+  wave_sync();
+  HB_STAMP(2);
 
   // ---- phase 2a: rules, one lane per game ---------------------------------------------------
-  const bool active = lane < nvalid && lane < G;
-  const long long gi = g0 + lane;
   uint32_t* const row = srow + lane * K::SWP;
   uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w6 = 0;
   uint64_t accw = 0, disc = 0;
@@ -249,14 +282,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
     accw = (static_cast<uint64_t>(row[5]) << 32) | row[4];
     disc = (static_cast<uint64_t>(row[9]) << 32) | row[8];
     if (mode == MODE_RESET) {
-      need_reset = a.mask ? a.mask[gi] != 0 : true;
+      need_reset = mask_in;
       keep_seats = false;
       reset_start = a.start_player;
     } else if (mode == MODE_STEP && ((w0 >> 19) & 3) == 0) {
       int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7;
       const int s = (w0 >> 13) & 7;
       int turns = (w0 >> 16) & 7, moves = (w0 >> 21) & 255;
-      const int uid = a.actions[gi];
+      const int uid = uid_in;
       int type = MV_PLAY, ci = 0, toff = 0, hcol = 0, hrank = 0;
       bool ok = uid >= 0 && uid < K::A;
       if (uid < H) { type = MV_DISCARD; ci = uid; }
@@ -383,6 +416,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
     out_score = score_now();
   }
 
+  HB_STAMP(3);
   // ---- phase 2b: wave-cooperative re-deal of finished / masked games -----------------------
   {
     unsigned long long todo = __ballot(need_reset);
@@ -398,12 +432,15 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
         uint32_t out[4];
         philox4x32_10(static_cast<uint32_t>(lane), episode, static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
                       static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), out);
-        const uint32_t key = out[0];
+        // sort key: 26 random bits, the deck position in the low 6 bits -> all keys distinct
+        const uint32_t key = (out[0] & ~63u) | static_cast<uint32_t>(lane);
+        // rank among the D keys: D scalar broadcasts (v_readlane with a constant lane) + compare + add-carry
         int rank = 0;
-        for (int i = 0; i < K::D; ++i) {
-          const uint32_t ki = __shfl(key, i);
-          rank += (ki < key || (ki == key && i < lane)) ? 1 : 0;
-        }
+        static_for<K::D>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          const uint32_t ki = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), i));
+          rank += ki < key ? 1 : 0;
+        });
         if (lane < K::D) {
           const int col = lane / K::CPC, k = lane - col * K::CPC;
           const int rk = k < 3 ? 0 : 1 + (k - 3) / 2;
@@ -412,7 +449,9 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       }
     }
   }
-  __syncthreads();
+  HB_STAMP(4);
+  wave_sync();
+  HB_STAMP(5);
 
   // ---- phase 2c: deal fresh games, encode, publish fields -----------------------------------
   if (active) {
@@ -571,7 +610,9 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
     const unsigned long long bad = __ballot(illegal);
     if (bad && lane == 0) atomicAdd(a.illegal, static_cast<unsigned long long>(__popcll(bad)));
   }
-  __syncthreads();
+  HB_STAMP(6);
+  wave_sync();
+  HB_STAMP(7);
 
   // ---- phase 3: LDS -> HBM, full-width coalesced stores -------------------------------------
   if (mode != MODE_OBSERVE) {
@@ -585,10 +626,13 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       dst[e] = v;
     }
   }
+  HB_STAMP(8);
   if (mode != MODE_RESET) {
     expand_rows<K::OBS_LEN>(obits, K::NWP, nvalid, a.obs + g0 * K::OBS_LEN, lane);
     expand_rows<K::A>(lbits, K::LW, nvalid, a.legal + g0 * K::A, lane);
   }
+  HB_STAMP(9);
+  HB_STAMP_REAL(11);
 }
 
 template <class K, int G>

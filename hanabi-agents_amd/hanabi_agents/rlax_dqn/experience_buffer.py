@@ -1,0 +1,116 @@
+"""Replay ring, resident in HBM.
+
+Same constructor, attributes and methods as the reference's numpy ring
+(hanabi_agents/rlax_dqn/experience_buffer.py:5-97): six preallocated arrays, `oldest_entry` /
+`size` / `capacity`, `get_update_indices`, `add_transitions` with wrap-around, `buf[indices]`
+-> `Transition`, uniform `sample`. The ring-pointer arithmetic is restated line by line (C-12);
+the storage is torch tensors on the agent's device, so inserting the N transitions of one env
+step and gathering a batch never cross PCIe (the reference's largest avoidable cost, SURVEY
+§3.4). Rewards are kept in float32 on the device (the reference stores float64, C-13) and are
+handed back as float64 by the numpy-facing accessors.
+
+Row order: `add_transitions` keeps the order of the rows it is given, exactly like the
+reference's slice assignments, so ring contents are comparable entry by entry.
+"""
+import numpy as np
+import torch
+
+from .transition import Transition
+
+
+def _dev(x, device, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype)
+    return torch.as_tensor(np.asarray(x)).to(device=device, dtype=dtype)
+
+
+class ExperienceBuffer:
+    """ExperienceBuffer stores transitions for training (device-resident)."""
+
+    def __init__(self, observation_len: int, action_len: int, reward_len: int, capacity: int, device=None, seed=0):
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        d = self.device
+        self._obs_tm1_buf = torch.zeros((capacity, observation_len), dtype=torch.int8, device=d)
+        self._act_tm1_buf = torch.zeros((capacity, 1), dtype=torch.int8, device=d)
+        self._obs_t_buf = torch.zeros((capacity, observation_len), dtype=torch.int8, device=d)
+        self._lms_t_buf = torch.zeros((capacity, action_len), dtype=torch.int8, device=d)
+        self._rew_t_buf = torch.zeros((capacity, reward_len), dtype=torch.float32, device=d)
+        self._terminal_t_buf = torch.zeros((capacity, 1), dtype=torch.bool, device=d)
+        self.oldest_entry = 0
+        self.capacity = capacity
+        self.size = 0
+        self._gen = torch.Generator(device=d).manual_seed(seed)
+
+    # ---- ring arithmetic (experience_buffer.py:21-24,46-81) ---------------------------------------
+    def get_update_indices(self, batch_size):
+        if self.oldest_entry + batch_size <= self.capacity:
+            return list(range(self.oldest_entry, self.oldest_entry + batch_size))
+        return list(range(self.oldest_entry, self.capacity)) + list(
+            range(0, batch_size - self.capacity + self.oldest_entry))
+
+    def _advance(self, batch_size):
+        """Returns the list of (buffer slice, batch slice) pairs and moves oldest_entry/size."""
+        start = self.oldest_entry
+        if start + batch_size <= self.capacity:
+            parts = [(slice(start, start + batch_size), slice(0, batch_size))]
+            if start + batch_size == self.capacity:
+                self.size = self.capacity
+            self.oldest_entry = (start + batch_size) % self.capacity
+            self.size = max(self.size, self.oldest_entry)
+        else:
+            tail = start + batch_size - self.capacity
+            # the reference writes rows [:batch-tail] at the end and the LAST `tail` rows at the front
+            parts = [(slice(start, self.capacity), slice(0, batch_size - tail)),
+                     (slice(0, tail), slice(batch_size - tail, batch_size))]
+            self.oldest_entry = tail
+            self.size = self.capacity
+        return parts
+
+    def add_transitions(self, observation_tm1, action_tm1, reward_t, observation_t, legal_moves_t, terminal_t):
+        """Append a batch (numpy arrays or torch tensors on any device); shapes as in the reference."""
+        d = self.device
+        cols = (
+            (self._obs_tm1_buf, _dev(observation_tm1, d, torch.int8)),
+            (self._act_tm1_buf, _dev(action_tm1, d, torch.int8).reshape(-1, 1)),
+            (self._rew_t_buf, _dev(reward_t, d, torch.float32).reshape(-1, self._rew_t_buf.shape[1])),
+            (self._obs_t_buf, _dev(observation_t, d, torch.int8)),
+            (self._lms_t_buf, _dev(legal_moves_t, d, torch.int8)),
+            (self._terminal_t_buf, _dev(terminal_t, d, torch.bool).reshape(-1, 1)),
+        )
+        batch_size = cols[0][1].shape[0]
+        if batch_size == 0:
+            return
+        if batch_size > self.capacity:
+            raise ValueError("batch larger than the replay capacity")
+        for dst, src in self._advance(batch_size):
+            for buf, val in cols:
+                buf[dst] = val[src]
+
+    # ---- access ---------------------------------------------------------------------------------
+    def gather_dev(self, indices: torch.Tensor) -> Transition:
+        """Batch as device tensors (the learner's path)."""
+        return Transition(
+            self._obs_tm1_buf.index_select(0, indices), self._act_tm1_buf.index_select(0, indices),
+            self._rew_t_buf.index_select(0, indices), self._obs_t_buf.index_select(0, indices),
+            self._lms_t_buf.index_select(0, indices), self._terminal_t_buf.index_select(0, indices))
+
+    def __getitem__(self, indices) -> Transition:
+        """Numpy view for reference-shaped callers: int8 / float64 / bool arrays (experience_buffer.py:83-87)."""
+        idx = _dev(np.asarray(indices, dtype=np.int64).reshape(-1), self.device, torch.int64)
+        t = self.gather_dev(idx)
+        return Transition(t.observation_tm1.cpu().numpy(), t.action_tm1.cpu().numpy(),
+                          t.reward_t.cpu().numpy().astype(np.float64), t.observation_t.cpu().numpy(),
+                          t.legal_moves_t.cpu().numpy(), t.terminal_t.cpu().numpy())
+
+    def sample_indices_dev(self, batch_size: int) -> torch.Tensor:
+        """Uniform WITH replacement over [0, size) (experience_buffer.py:96; C-11), own generator."""
+        if self.size == 0:
+            raise ValueError("cannot sample from an empty buffer")
+        return torch.randint(0, self.size, (batch_size,), device=self.device, generator=self._gen)
+
+    def sample_dev(self, batch_size: int) -> Transition:
+        return self.gather_dev(self.sample_indices_dev(batch_size))
+
+    def sample(self, batch_size: int) -> Transition:
+        return self[self.sample_indices_dev(batch_size).cpu().numpy()]

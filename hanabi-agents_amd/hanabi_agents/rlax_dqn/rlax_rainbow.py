@@ -1,0 +1,284 @@
+"""DQNAgent — the drop-in agent API of the reference, MI355X-native underneath.
+
+Method names, argument meaning and bookkeeping follow `hanabi_agents.rlax_dqn.DQNAgent`
+(hanabi_agents/rlax_dqn/rlax_rainbow.py:220-365):
+
+    DQNAgent(observation_spec, action_spec, params=RlaxRainbowParams())
+    explore(observations) / exploit(observations)       -> int actions [N]
+    add_experience_first(observations, step_types)      FIRST rows seed last_obs
+    add_experience(observations, actions, rewards, step_types)
+    update()                                            one gradient step
+    save_weights(path, fname_part) / restore_weights(online_file, trg_file)
+    requires_vectorized_observation()                   -> True
+
+`observations` is the session's tuple whose element [1] is (obs [N, obs_len], legal [N, A])
+(rlax_rainbow.py:278,285,293,298). numpy inputs behave exactly like the reference (copied to the
+device on entry, numpy actions returned). torch CUDA tensors are taken zero-copy and actions come
+back as a CUDA int32 tensor — the path the self-play driver uses so that an env step, the policy,
+the replay insert and the learner never leave the GPU.
+
+What runs where: the network GEMMs, softmax/expectation, C51 projection, Adam — PyTorch-ROCm
+(rocBLAS/hipBLASLt MFMA GEMMs); prioritized sampling / priority update — the HIP sum tree of
+hanabi_hip; replay ring — device tensors. Quirks of the reference that are kept or made
+switchable are listed in DESIGN.md §7.
+"""
+import os
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import learning as L
+from .experience_buffer import ExperienceBuffer
+from .noisy_mlp import NoisyMLP, PlainMLP
+from .params import RlaxRainbowParams
+from .priority_buffer import PriorityBuffer
+
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def _shape_of(spec):
+    return tuple(spec.shape)
+
+
+class DQNPolicy:
+    """Greedy and legal-epsilon-greedy action selection (rlax_rainbow.py:30-150)."""
+
+    @staticmethod
+    def q_values(network, atoms, obs, legal, distributional=True):
+        """q [N, A] with illegal moves at -inf (rlax_rainbow.py:113-119,141-147)."""
+        out = network(obs)
+        if distributional:
+            n_actions, n_atoms = atoms.shape
+            q = L.expected_q(out.view(-1, n_actions, n_atoms), atoms)
+        else:
+            q = out
+        return torch.where(legal.bool(), q, torch.full_like(q, float("-inf")))
+
+    @staticmethod
+    def sample(q, legal, epsilon, u_explore, u_pick):
+        """Legal epsilon-greedy sample (rlax_rainbow.py:34-71).
+
+        The reference mixes (1-eps) * uniform-over-argmax-ties + eps * uniform-over-legal and samples the
+        mixture through a cumulative sum with a round-off guard (C-14). The same distribution is drawn
+        here without floating-point cumsums: with probability eps pick the k-th legal move, otherwise
+        the k-th arg-max tie, k uniform. u_explore, u_pick: uniforms in [0,1) of shape [N].
+        """
+        legal_b = legal.bool()
+        greedy = (q == q.max(dim=-1, keepdim=True).values) & legal_b
+        pool = torch.where((u_explore < epsilon)[:, None], legal_b, greedy)
+        count = pool.sum(dim=-1)
+        k = torch.clamp((u_pick * count).long(), max=torch.clamp(count - 1, min=0))
+        hit = (torch.cumsum(pool.int(), dim=-1) == (k + 1)[:, None]) & pool
+        return torch.argmax(hit.int(), dim=-1).to(torch.int32)
+
+    @staticmethod
+    def policy(network, atoms, epsilon, obs, legal, u_explore, u_pick, distributional=True):
+        q = DQNPolicy.q_values(network, atoms, obs, legal, distributional)
+        return q, DQNPolicy.sample(q, legal, epsilon, u_explore, u_pick)
+
+    @staticmethod
+    def eval_policy(network, atoms, obs, legal, u_pick, distributional=True):
+        """rlax.greedy().sample: uniform among arg-max ties (rlax_rainbow.py:125-150)."""
+        q = DQNPolicy.q_values(network, atoms, obs, legal, distributional)
+        return DQNPolicy.sample(q, legal, 0.0, torch.ones_like(u_pick), u_pick)
+
+
+class DQNLearning:
+    @staticmethod
+    def loss(online, target, atoms, transitions, discount, prios, beta_is, mask_terminal=False, distributional=True):
+        """mean(td * w_IS) and the per-sample |td| that become the new priorities (rlax_rainbow.py:187-200)."""
+        obs_tm1 = transitions.observation_tm1
+        obs_t = transitions.observation_t
+        a_tm1 = transitions.action_tm1[:, 0].long()
+        r_t = transitions.reward_t[:, 0].to(torch.float32)
+        term = transitions.terminal_t[:, 0]
+        w = L.is_weights(prios, beta_is)
+        if distributional:
+            a, k = atoms.shape
+            logits_tm1 = online(obs_tm1).view(-1, a, k)
+            with torch.no_grad():
+                logits_t = target(obs_t).view(-1, a, k)
+                logits_sel = online(obs_t).view(-1, a, k)
+            td = L.categorical_double_q_td(logits_tm1, a_tm1, r_t, discount, atoms, logits_t, logits_sel,
+                                           term if mask_terminal else None)
+            return torch.mean(td * w), torch.abs(td).detach()
+        # scalar double-DQN of the older agent (rlax_dqn.py:170-205): IS-weighted l2 with clipped gradient
+        q_tm1 = online(obs_tm1)
+        with torch.no_grad():
+            q_t = target(obs_t)
+            q_sel = online(obs_t)
+        td = L.double_q_td(q_tm1, a_tm1, r_t, discount, q_t, q_sel, term)
+        return L.clip_gradient(torch.mean(w * 0.5 * td * td)), torch.abs(td).detach()
+
+
+class DQNAgent:
+    def __init__(self, observation_spec, action_spec, params: RlaxRainbowParams = RlaxRainbowParams(), device=None,
+                 process_group=None):
+        if not callable(params.epsilon):
+            eps = params.epsilon
+            params = params._replace(epsilon=lambda ts: eps)
+        if not callable(params.beta_is):
+            beta = params.beta_is
+            params = params._replace(beta_is=lambda ts: beta)
+        self.params = params
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.process_group = process_group  # torch.distributed group for data-parallel gradient all-reduce
+        n_games, obs_len = _shape_of(observation_spec)
+        self.n_actions = int(action_spec.num_values)
+        self.obs_len = obs_len
+        cd = _DTYPES[params.compute_dtype]
+        self.distributional = bool(params.distributional)
+
+        # Q-network: online and target copies (the reference aliases them until the first update; here the
+        # target is a separate module holding equal values, which is observationally identical, C-10)
+        def build():
+            if self.distributional:
+                return NoisyMLP(obs_len, tuple(params.layers) + (self.n_actions * params.n_atoms,), seed=params.seed,
+                                compute_dtype=cd)
+            return PlainMLP(obs_len, tuple(params.layers) + (self.n_actions,), seed=params.seed, compute_dtype=cd)
+
+        self.online = build().to(self.device)
+        self.target = build().to(self.device)
+        self.target.load_state_dict(self.online.state_dict())
+        for p in self.target.parameters():
+            p.requires_grad_(False)
+        self.atoms = torch.linspace(-params.atom_vmax, params.atom_vmax, params.n_atoms, device=self.device).repeat(
+            self.n_actions, 1)  # [A, K] (rlax_rainbow.py:253-254)
+        # optix.adam(lr, eps=3.125e-5) has torch.optim.Adam's form, eps outside the sqrt
+        self.optimizer = torch.optim.Adam(self.online.parameters(), lr=params.learning_rate, betas=(0.9, 0.999),
+                                          eps=3.125e-5)
+        self.train_step = 0
+        buf = PriorityBuffer if params.use_priority else ExperienceBuffer
+        self.experience = buf(obs_len, self.n_actions, 1, params.experience_buffer_size, device=self.device,
+                              seed=params.seed)
+        # the reference keeps last_obs as float64 [N, obs_len] (172 MB at 32k games, C-13); int8 here
+        self.last_obs = torch.zeros((n_games, obs_len), dtype=torch.int8, device=self.device)
+        self.requires_vectorized_observation = lambda: True
+        self._gen = torch.Generator(device=self.device).manual_seed(params.seed + 1)
+        self.last_loss = None
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _unpack(self, observations) -> Tuple[torch.Tensor, torch.Tensor, bool]:
+        obs, legal = observations[1]
+        on_device = isinstance(obs, torch.Tensor)
+        if on_device:
+            return obs.to(self.device), legal.to(self.device), True
+        return (torch.as_tensor(np.asarray(obs)).to(self.device), torch.as_tensor(np.asarray(legal)).to(self.device), False)
+
+    def _vec(self, x, dtype):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype)
+        return torch.as_tensor(np.asarray(x)).to(device=self.device, dtype=dtype)
+
+    def _uniform(self, n):
+        return torch.rand(n, device=self.device, generator=self._gen)
+
+    def _net_input(self, obs):
+        return obs.to(torch.float32)
+
+    # ---- acting (rlax_rainbow.py:277-290) ---------------------------------------------------------------
+    @torch.no_grad()
+    def exploit(self, observations):
+        obs, legal, on_device = self._unpack(observations)
+        if self.params.resample_noise:
+            self.online.resample()
+        actions = DQNPolicy.eval_policy(self.online, self.atoms, self._net_input(obs), legal, self._uniform(obs.shape[0]),
+                                        self.distributional)
+        return actions if on_device else actions.cpu().numpy()
+
+    @torch.no_grad()
+    def explore(self, observations):
+        obs, legal, on_device = self._unpack(observations)
+        if self.params.resample_noise:
+            self.online.resample()
+        n = obs.shape[0]
+        _, actions = DQNPolicy.policy(self.online, self.atoms, float(self.params.epsilon(self.train_step)),
+                                      self._net_input(obs), legal, self._uniform(n), self._uniform(n), self.distributional)
+        return actions if on_device else actions.cpu().numpy()
+
+    # ---- recording (rlax_rainbow.py:292-308) --------------------------------------------------------------
+    def add_experience_first(self, observations, step_types):
+        obs, _, _ = self._unpack(observations)
+        first = self._vec(step_types, torch.int64) == 0
+        self.last_obs = torch.where(first[:, None], obs.to(torch.int8), self.last_obs)
+
+    def add_experience(self, observations, actions, rewards, step_types):
+        obs, legal, _ = self._unpack(observations)
+        st = self._vec(step_types, torch.int64)
+        not_first = st != 0
+        idx = torch.nonzero(not_first, as_tuple=False)[:, 0]  # keeps row order, like boolean-mask indexing
+        obs8 = obs.to(torch.int8)
+        if idx.numel():
+            self.experience.add_transitions(
+                self.last_obs.index_select(0, idx),
+                self._vec(actions, torch.int64).index_select(0, idx).reshape(-1, 1),
+                self._vec(rewards, torch.float32).index_select(0, idx).reshape(-1, 1),
+                obs8.index_select(0, idx),
+                legal.index_select(0, idx),
+                (st.index_select(0, idx) == 2).reshape(-1, 1))
+        self.last_obs = torch.where(not_first[:, None], obs8, self.last_obs)
+
+    # ---- learning (rlax_rainbow.py:310-339) -----------------------------------------------------------------
+    def _sample(self):
+        b = self.params.train_batch_size
+        if self.params.use_priority:
+            return self.experience.sample_batch_dev(b)
+        indices = self.experience.sample_indices_dev(b)
+        prios = torch.ones(b, dtype=torch.float64, device=self.device)  # rlax_rainbow.py:318-319
+        return indices, prios, self.experience.gather_dev(indices)
+
+    def update(self):
+        """Make one training step."""
+        indices, prios, tr = self._sample()
+        tr = tr._replace(observation_tm1=self._net_input(tr.observation_tm1), observation_t=self._net_input(tr.observation_t))
+        if self.params.resample_noise:
+            self.online.resample()
+            self.target.resample()
+        loss, new_prios = DQNLearning.loss(self.online, self.target, self.atoms, tr, self.params.discount, prios,
+                                           float(self.params.beta_is(self.train_step)), self.params.mask_terminal,
+                                           self.distributional)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self._allreduce_gradients()
+        self.optimizer.step()
+        self.last_loss = loss.detach()
+        if self.params.use_priority:
+            self.experience.update_priorities_dev(indices, new_prios)
+        if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
+            self.target.load_state_dict(self.online.state_dict())
+        self.train_step += 1
+
+    def _allreduce_gradients(self):
+        """Data parallelism: ONE flat all-reduce (sum / world) of the gradient over RCCL."""
+        import torch.distributed as dist
+
+        if self.process_group is None and not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.process_group)
+        if world == 1:
+            return
+        grads = [p.grad for p in self.online.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        flat /= world
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    # ---- misc --------------------------------------------------------------------------------------------
+    def __repr__(self):
+        return f"<rlax_dqn.DQNAgent(params={self.params})>"
+
+    def save_weights(self, path, fname_part):
+        """Writes rlax_rainbow_<part>_{online,target}.pkl like the reference (rlax_rainbow.py:344-357); the
+        payload is a torch state_dict (tensors only), not a pickle of jax arrays."""
+        torch.save(self.online.state_dict(), os.path.join(path, "rlax_rainbow_" + fname_part + "_online.pkl"))
+        torch.save(self.target.state_dict(), os.path.join(path, "rlax_rainbow_" + fname_part + "_target.pkl"))
+
+    def restore_weights(self, online_weights_file, trg_weights_file):
+        self.online.load_state_dict(torch.load(online_weights_file, map_location=self.device, weights_only=True))
+        self.target.load_state_dict(torch.load(trg_weights_file, map_location=self.device, weights_only=True))

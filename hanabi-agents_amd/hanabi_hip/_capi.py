@@ -37,7 +37,8 @@ def make_config(game="Hanabi-Full", players=2, flags=0):
 
 
 def library_path():
-    return os.path.join(_HERE, "libhanabi_hip.so")
+    # HANABI_HIP_LIB lets scripts/env_stamps.py load the diagnostic (-DHB_STAMPS) build of the same ABI
+    return os.environ.get("HANABI_HIP_LIB") or os.path.join(_HERE, "libhanabi_hip.so")
 
 
 # name -> (restype, argtypes); one entry per symbol declared in include/hanabi_hip.h

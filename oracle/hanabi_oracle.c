@@ -106,13 +106,13 @@ void orc_shuffled_deck(const hb_config* cfg, uint64_t seed, uint64_t game_id, ui
     uint32_t ctr[4] = {(uint32_t)j, episode, (uint32_t)game_id, (uint32_t)(game_id >> 32)};
     uint32_t out[4];
     orc_philox4x32(ctr, key, out);
-    keys[j] = out[0];
+    keys[j] = (out[0] & ~63u) | (uint32_t)j; /* 26 random bits, ties broken by position: keys are distinct */
   }
-  /* position of card j = number of cards that sort before it by (key, j) */
+  /* position of card j = number of cards whose key sorts before its key */
   for (int j = 0; j < D; ++j) {
     int rank = 0;
     for (int i = 0; i < D; ++i)
-      if (keys[i] < keys[j] || (keys[i] == keys[j] && i < j)) ++rank;
+      if (keys[i] < keys[j]) ++rank;
     deck[rank] = canon[j];
   }
 }

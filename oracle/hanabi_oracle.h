@@ -29,7 +29,7 @@ extern "C" {
 /* ---- Philox4x32-10 (Salmon et al., SC'11), shared definition of all randomness ------ */
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* deck of (seed, global game id, episode): cards sorted by (philox(...)[0], position) */
+/* deck of (seed, global game id, episode): cards sorted by the key (philox(j, episode, game)[0] & ~63) | j */
 void orc_shuffled_deck(const hb_config* cfg, uint64_t seed, uint64_t game_id, uint32_t episode, uint8_t* deck);
 
 /* ---- env ----------------------------------------------------------------------------- */
