@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native Hanabi self-play + Rainbow-DQN path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2]): 2-player full Hanabi, 32 768 parallel games PER GPU (weak
+scaling: games shard embarrassingly, global game ids = rank * 32768 + local), two Rainbow agents
+(C51 + noisy nets + PER on the GPU sum tree, batch 256), one per seat. A "step" is one lock-step
+move of all the rank's games through the whole hot path:
+
+    replay insert of the acting seat's transitions -> policy forward + legal eps-greedy sample
+    -> fused env step / legal mask / canonical encoder kernel -> `--updates-per-step` learner
+    updates (PER sample, 3 forwards + backward, Adam, priority update, RCCL grad all-reduce)
+
+`value` = env-steps/s over all ranks inside the timed region; grad-steps/s is reported next to it.
+Extra objects on the same JSON line:
+  roofline      the env kernel (the north-star HBM-bound kernel): algorithmic bytes per launch
+                (obs_len + A + 9 + 2*STATE_BYTES = 943 B per game) / its average
+                dispatch duration, measured live on every launch of the timed region with HIP
+                events attached to the dispatch (hb_env_set_profile_events)
+  roofline_qnet MFMA side: algorithmic FLOPs of actor forward + learner step / their event time
+  cpu_baseline  the CPU oracle (oracle/, a port: the reference's env is not in its tree) on the
+                host cores, bounded sample of the same workload, rank 0 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hanabi-agents_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"float32": 157.3, "bfloat16": 2500.0, "float16": 2500.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--games", type=int, default=32768, help="games per GPU")
+    ap.add_argument("--players", type=int, default=2)
+    ap.add_argument("--updates-per-step", type=int, default=1)
+    ap.add_argument("--compute-dtype", default="bfloat16", choices=list(MFMA_PEAK_TFLOPS))
+    ap.add_argument("--games-per-wave", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-games", type=int, default=4096)
+    ap.add_argument("--cpu-sample-steps", type=int, default=150)
+    ap.add_argument("--env-only", action="store_true", help="random-legal policy, no agents (kernel-only rate)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle env (step + legal + encode) on the host: same game config, Philox decks and random-legal
+    policy; 1 thread and all cores. Bounded to ~10-30 s."""
+    from oracle import oracle_py as O
+
+    n, steps = args.cpu_sample_games, args.cpu_sample_steps
+    flags = O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads in (("1", 1), ("all", cores)):
+        env = O.OracleEnv(O.make_config("Hanabi-Full", args.players, flags), n, seed=1234, threads=threads)
+        legal = env.observe()["legal"]
+        t0 = time.perf_counter()
+        for t in range(steps):
+            act = O.random_legal_actions(legal, 4321, t)
+            legal = env.step(act)["legal"]
+        out[label] = n * steps / (time.perf_counter() - t0)
+    best = max(out.values())
+    return {"value": best, "unit": "env-steps/s", "cores": cores if out["all"] >= out["1"] else 1, "kind": "port",
+            "single_thread_value": out["1"], "all_cores_value": out["all"],
+            "sample": f"{n} games x {steps} lock-step moves of the same 2-player full Hanabi workload "
+                      f"(oracle/hanabi_oracle.c: step + legal mask + canonical encoder, random-legal policy)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    n = args.games
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", args.players, flags), n_games=n, seed=1234,
+                               first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device)
+    bytes_per_step = env.obs_len + env.num_actions + 9 + 2 * env.state_words * 4
+
+    agents = []
+    session = None
+    if not args.env_only:
+        params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank)
+        agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
+                           params._replace(seed=1234 + 17 * s), device=device) for s in range(args.players)]
+        if world > 1:  # identical initial weights on every rank (data parallel)
+            for a in agents:
+                for t in list(a.online.parameters()) + list(a.online.buffers()):
+                    dist.broadcast(t.data, 0)
+                a.target.load_state_dict(a.online.state_dict())
+        session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step)
+
+    act = torch.empty(n, dtype=torch.int32, device=device)
+    draw = [0]
+
+    def one_step():
+        if session is not None:
+            session.step()
+        else:
+            env.random_legal_actions(4321, draw[0], out=act)
+            draw[0] += 1
+            env.step(act)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    # live per-dispatch timing of the env kernel inside the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:  # torch creates the HIP event on first record; do it outside the timed region
+        a.record()
+        b.record()
+    grad0 = session.grad_steps if session else 0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        env.set_profile_events(*ev[k])
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.set_profile_events(None, None)
+    grad_steps = (session.grad_steps - grad0) if session else 0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    achieved = n * bytes_per_step / kernel_avg_s / 1e9
+    line = {
+        "metric": "env_steps_per_sec",
+        "value": world * n * args.steps / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8" if args.env_only else f"u8 env/encoder + {args.compute_dtype} Q-net GEMM (fp32 accumulate, fp32 master weights)",
+        "data": "synthetic",
+        "config": {
+            "workload": ("2-player full Hanabi, 32 768 envs, Rainbow (PER sum_tree + noisy C51) on 1 MI355X"
+                         if (n == 32768 and args.players == 2) else f"{args.players}-player full Hanabi, {n} envs per GPU"),
+            "games_per_gpu": n, "players": args.players, "train_batch": 256, "updates_per_step": args.updates_per_step,
+            "policy": "random-legal (env only)" if args.env_only else "agent eps-greedy (eps 0.1)",
+            "parallelism": f"dp{world}: games sharded, RCCL gradient all-reduce",
+        },
+        "grad_steps_per_sec": world * 0 + (grad_steps / dt if grad_steps else 0.0),
+        "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n,
+                     "avg_launch_us": kernel_avg_s * 1e6, "median_launch_us": kernel_ms[len(kernel_ms) // 2] * 1e3,
+                     "kernel_only_env_steps_per_sec": n / kernel_avg_s},
+    }
+    # HBM traffic of the same kernel/config from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
+    # correction + WRITE_SIZE; profiles/): PMC counters cannot be read from inside this process
+    pmc = os.path.join(ROOT, "profiles", "r01", "env_kernel_pmc_traffic.json")
+    if n == 32768 and args.players == 2 and os.path.exists(pmc):
+        line["roofline"]["traffic"] = json.load(open(pmc))["per_launch_bytes"]["total"]
+        line["roofline"]["traffic_source"] = "profiles/r01/env_kernel_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+    if session is not None:
+        line["mean_episode_score"] = session.mean_score()
+        line["roofline_qnet"] = qnet_roofline(agents[0], env, args)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def qnet_roofline(agent, env, args):
+    """MFMA side: time the actor forward (N rows) and one learner update with events; FLOPs are the
+    ALGORITHMIC ones of SURVEY §8(d) (plain + noisy GEMM per layer), although the merged-weight form
+    executes half of the forward matrix FLOPs."""
+    n = env.n
+    hidden = agent.params.layers[0]
+    fwd_flop = 4.0 * (env.obs_len * hidden + hidden * env.num_actions * agent.params.n_atoms)  # per sample
+    obs = (None, (env.obs, env.legal))
+    for _ in range(3):
+        agent.explore(obs)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    reps = 10
+    for _ in range(reps):
+        agent.explore(obs)
+    b.record()
+    torch.cuda.synchronize()
+    actor_s = a.elapsed_time(b) / 1e3 / reps
+    a.record()
+    for _ in range(reps):
+        agent.update()
+    b.record()
+    torch.cuda.synchronize()
+    learn_s = a.elapsed_time(b) / 1e3 / reps
+    peak = MFMA_PEAK_TFLOPS[args.compute_dtype]
+    actor_tf = fwd_flop * n / actor_s / 1e12
+    learn_tf = 5.0 * 256 * fwd_flop / learn_s / 1e12
+    return {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "dtype": args.compute_dtype,
+            "actor_forward": {"rows": n, "algorithmic_gflop": fwd_flop * n / 1e9, "ms": actor_s * 1e3, "achieved": actor_tf,
+                              "frac": actor_tf / peak},
+            "learner_update": {"batch": 256, "algorithmic_gflop": 5.0 * 256 * fwd_flop / 1e9, "ms": learn_s * 1e3,
+                               "achieved": learn_tf, "frac": learn_tf / peak, "grad_steps_per_sec_alone": 1.0 / learn_s}}
+
+
+if __name__ == "__main__":
+    main()

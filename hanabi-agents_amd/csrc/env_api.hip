@@ -63,6 +63,7 @@ struct hb_env {
   const uint8_t* decks;
   int gpw;
   int device;
+  hipEvent_t ev_start, ev_stop;
 };
 
 using hb::fail;
@@ -115,7 +116,8 @@ int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t 
   e->seed = seed;
   e->first_gid = first_game_id;
   e->decks = nullptr;
-  e->gpw = 64;
+  e->gpw = 16;
+  e->ev_start = e->ev_stop = nullptr;
   HB_HIP_OR(hipGetDevice(&e->device), delete e);
   const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
@@ -149,6 +151,14 @@ int hb_env_set_games_per_wave(hb_env* e, int32_t g) {
   return HB_OK;
 }
 
+int hb_env_set_profile_events(hb_env* e, void* start_event, void* stop_event) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if ((start_event == nullptr) != (stop_event == nullptr)) return fail(HB_ERR_INVALID, "pass both events or neither");
+  e->ev_start = static_cast<hipEvent_t>(start_event);
+  e->ev_stop = static_cast<hipEvent_t>(stop_event);
+  return HB_OK;
+}
+
 static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.state = e->state;
   a.decks = e->decks;
@@ -157,6 +167,8 @@ static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.seed = e->seed;
   a.first_gid = e->first_gid;
   a.flags = e->cfg.flags;
+  a.ev_start = e->ev_start;
+  a.ev_stop = e->ev_stop;
   hb::LaunchFn fn = e->gpw == 16 ? e->var->g16 : (e->gpw == 32 ? e->var->g32 : e->var->g64);
   fn(a, static_cast<hipStream_t>(stream));
   HB_HIP(hipGetLastError());

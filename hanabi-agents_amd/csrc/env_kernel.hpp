@@ -24,6 +24,7 @@
 // for 2-player full Hanabi).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <utility>
 
@@ -52,6 +53,7 @@ struct EnvArgs {
   int mode;
   int start_player;
   unsigned long long* stamps;  // diagnostic builds only (-DHB_STAMPS): 12 u64 per wavefront
+  hipEvent_t ev_start, ev_stop;  // host-side only: optional per-dispatch timing events
 };
 
 // In-kernel phase stamps (cdna_hip_programming.md §7): compiled in only with -DHB_STAMPS, into a
@@ -640,7 +642,10 @@ void launch_env(const EnvArgs& a, hipStream_t stream) {
   const long long per_block = 4LL * G;
   const unsigned blocks = static_cast<unsigned>((a.n + per_block - 1) / per_block);
   if (blocks == 0) return;
-  hipLaunchKernelGGL((env_kernel<K, G>), dim3(blocks), dim3(256), 0, stream, a);
+  if (a.ev_start && a.ev_stop)
+    hipExtLaunchKernelGGL((env_kernel<K, G>), dim3(blocks), dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, a);
+  else
+    hipLaunchKernelGGL((env_kernel<K, G>), dim3(blocks), dim3(256), 0, stream, a);
 }
 
 using LaunchFn = void (*)(const EnvArgs&, hipStream_t);

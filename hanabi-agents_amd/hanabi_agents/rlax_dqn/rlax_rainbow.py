@@ -220,6 +220,17 @@ class DQNAgent:
                 (st.index_select(0, idx) == 2).reshape(-1, 1))
         self.last_obs = torch.where(not_first[:, None], obs8, self.last_obs)
 
+    def add_experience_dense(self, observations, actions, rewards, step_types):
+        """add_experience for callers that guarantee no FIRST rows (lock-step self-play after the first
+        round): every row is a transition, so nothing is compacted and no device->host sync happens."""
+        obs, legal, _ = self._unpack(observations)
+        obs8 = obs.to(torch.int8)
+        st = self._vec(step_types, torch.int64)
+        self.experience.add_transitions(self.last_obs, self._vec(actions, torch.int64).reshape(-1, 1),
+                                        self._vec(rewards, torch.float32).reshape(-1, 1), obs8, legal,
+                                        (st == 2).reshape(-1, 1))
+        self.last_obs.copy_(obs8)  # the caller's buffer is rewritten in place by the next env step
+
     # ---- learning (rlax_rainbow.py:310-339) -----------------------------------------------------------------
     def _sample(self):
         b = self.params.train_batch_size

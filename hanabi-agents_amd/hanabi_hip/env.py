@@ -61,6 +61,16 @@ class HanabiEnv:
     def set_games_per_wave(self, g):
         K.check(self.L.hb_env_set_games_per_wave(self.h, int(g)))
 
+    def set_profile_events(self, start=None, stop=None):
+        """torch.cuda.Event(enable_timing=True) pair that every following env launch records its own
+        begin/end into (dispatch timestamps, like rocprofv3's kernel trace); None, None disables."""
+        if start is None:
+            K.check(self.L.hb_env_set_profile_events(self.h, None, None))
+            return
+        if not (start.cuda_event and stop.cuda_event):
+            raise K.HbError("record() the events once before passing them (torch creates the HIP event lazily)")
+        K.check(self.L.hb_env_set_profile_events(self.h, C.c_void_p(start.cuda_event), C.c_void_p(stop.cuda_event)))
+
     def set_decks(self, decks):
         """Explicit decks [N, deck_size] uint8 (first card dealt first), or None for Philox shuffles."""
         if decks is None:

@@ -1,0 +1,69 @@
+"""SelfPlaySession — minimal lock-step self-play driver.
+
+The reference ships no driver: its agents are passive objects called by the authors' external
+`hanabi_multiagent_framework` session. This is the smallest loop that exercises the
+agent API the way that session does, entirely on the GPU:
+
+    seat = t mod P                       (all N games act with the same seat: HB_FLAG_RESET_START_NEXT)
+    agent[seat].add_experience_first(obs, step_types)     rows whose seat has no move pending yet
+    agent[seat].add_experience(obs, last_actions[seat], agent_rewards, step_types)
+    actions = agent[seat].explore(obs)
+    env.step(actions)                    -> obs / legal / per-seat reward + step type for seat+1
+    agent[seat].update()  x updates_per_step
+
+Per-seat reward accumulation across the other seats' turns, FIRST/MID/LAST generation and the
+re-deal of finished games happen inside the env kernel (include/hanabi_hip.h, hb_env_step), so
+the driver itself moves no data. An agent's `obs_t` is its own next turn; when its episode ended in
+between, step type is LAST and `obs_t` is already the first observation of the fresh game (which
+the learner ignores when `mask_terminal` is on).
+"""
+import torch
+
+
+class SelfPlaySession:
+    def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None):
+        assert len(agents) == env.players, "one agent per seat"
+        self.env = env
+        self.agents = list(agents)
+        self.updates_per_step = int(updates_per_step)
+        self.t = 0
+        self.last_actions = [torch.zeros(env.n, dtype=torch.int32, device=env.device) for _ in agents]
+        self.min_replay = min_replay
+        self.train_seats = set(range(env.players)) if train_seats is None else set(train_seats)
+        self.env_steps = 0
+        self.grad_steps = 0
+        self.episodes = torch.zeros((), dtype=torch.int64, device=env.device)
+        self.score_sum = torch.zeros((), dtype=torch.int64, device=env.device)
+
+    def step(self, train=True, explore=True):
+        env = self.env
+        seat = self.t % env.players
+        agent = self.agents[seat]
+        observations = (None, (env.obs, env.legal))
+        if self.t < env.players:
+            # only during the first round can a seat be without a pending move (step type FIRST)
+            agent.add_experience_first(observations, env.agent_step_type)
+            agent.add_experience(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
+        else:
+            agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
+        actions = agent.explore(observations) if explore else agent.exploit(observations)
+        self.last_actions[seat] = actions
+        env.step(actions)
+        self.episodes += env.terminal.sum()
+        self.score_sum += (env.score * env.terminal).sum()
+        self.env_steps += env.n
+        if train and seat in self.train_seats:
+            need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
+            if agent.experience.size >= need:
+                for _ in range(self.updates_per_step):
+                    agent.update()
+                    self.grad_steps += 1
+        self.t += 1
+
+    def run(self, steps, train=True):
+        for _ in range(steps):
+            self.step(train=train)
+
+    def mean_score(self):
+        e = int(self.episodes.item())
+        return float(self.score_sum.item()) / e if e else float("nan")

@@ -144,6 +144,11 @@ int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_
 /* Tuning knob for measurements: games handled per 64-lane wavefront (16, 32 or 64).    */
 int hb_env_set_games_per_wave(hb_env* env, int32_t g);
 
+/* Measurement hook: when both are non-NULL (hipEvent_t handles), every following env kernel
+ * launch records its own start/stop into them (hipExtLaunchKernelGGL), i.e. the dispatch's
+ * begin/end timestamps rather than a pair of stream markers. NULL, NULL turns it off.      */
+int hb_env_set_profile_events(hb_env* env, void* start_event, void* stop_event);
+
 /* ---- GPU-resident sum tree ------------------------------------------------------------
  * Replaces sum_tree.SumTreef (sum_tree/sum_tree/include/sum_tree.h:22-130 through
  * sum_tree/sum_tree/src/sum_tree_py.cc:9-22). Flat fp32 heap array in HBM: node 1 is the
