@@ -72,11 +72,11 @@ class NoisyLinear(nn.Module):
         cd = self.compute_dtype
         if merged:
             W, bias = self.effective(eps_w, eps_b)
-            y = torch.matmul(x.to(cd), W.to(cd)).float()
+            y = torch.matmul(x.to(cd), W.to(cd)).to(W.dtype)
             return y if bias is None else y + bias
         eps_w = self.eps_w if eps_w is None else eps_w
-        y = torch.matmul(x.to(cd), self.w.to(cd)).float()
-        y_noisy = torch.matmul(x.to(cd), (self.w_mu + self.w_sigma * eps_w).to(cd)).float()
+        y = torch.matmul(x.to(cd), self.w.to(cd)).to(self.w.dtype)
+        y_noisy = torch.matmul(x.to(cd), (self.w_mu + self.w_sigma * eps_w).to(cd)).to(self.w.dtype)
         if self.with_bias:
             eps_b = self.eps_b if eps_b is None else eps_b
             y = y + self.b
@@ -137,7 +137,7 @@ class PlainMLP(nn.Module):
         out = x
         last = len(self.weights) - 1
         for i, (w, b) in enumerate(zip(self.weights, self.biases)):
-            out = torch.matmul(out.to(self.compute_dtype), w.to(self.compute_dtype)).float() + b
+            out = torch.matmul(out.to(self.compute_dtype), w.to(self.compute_dtype)).to(w.dtype) + b
             if i < last:
                 out = torch.relu(out)
         return out
