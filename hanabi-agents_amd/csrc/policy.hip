@@ -1,0 +1,258 @@
+// policy.hip — fused action selection for the actor: one pass over the C51 logits.
+//
+// Replaces the tail of DQNPolicy.policy / eval_policy (hanabi_agents/rlax_dqn/rlax_rainbow.py:93-150):
+//   probs = softmax(logits, -1); q = mean(probs * atoms, -1)        rlax_rainbow.py:117-118,144-145 (mean, App. C-3)
+//   q = where(legal, q, -inf)                                       rlax_rainbow.py:119,147
+//   legal epsilon-greedy / greedy sample with uniform tie-breaking  rlax_rainbow.py:34-71,122,150
+// A dozen elementwise / scan / reduce launches over the [N, A, K] logits (133 MB at 32 768 games) become one
+// HBM-bound kernel that reads the logits once.
+//
+// Mapping: a wavefront owns GPW = 64 / A consecutive games; it stages their A*K logits through LDS with
+// coalesced 4-element loads, then lane (game, action) reduces its K atoms from LDS (row stride K is odd ->
+// conflict-free), and the first lane of each game picks the move. Randomness: Philox4x32-10 keyed by
+// (seed; draw, global game id): word 0 decides explore-vs-greedy, word 1 picks the k-th candidate, so the
+// distribution is exactly (1-eps) * uniform(argmax ties) + eps * uniform(legal) (C-14 without float cumsums).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/hanabi_hip.h"
+#include "common.hpp"
+#include "env_kernel.hpp"  // philox4x32_10
+
+using hb::fail;
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <>
+__device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+
+constexpr int MAX_WAVE_ELEMS = 64 * 64;  // LDS floats per wavefront: covers A*K <= 4096 per game group
+
+template <typename T>
+__global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logits, const int8_t* __restrict__ legal,
+                                                     const float* __restrict__ support, long long n, int A, int K,
+                                                     float epsilon, unsigned long long seed, unsigned long long draw,
+                                                     long long first_gid, int32_t* __restrict__ actions,
+                                                     float* __restrict__ q_out) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gpw = 64 / A;
+  const int per_wave = gpw * A * K;
+  float* buf = lds + wave * (per_wave + 64);
+  float* qbuf = buf + per_wave;
+  const long long g0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * gpw;
+  if (g0 >= n) return;
+  const long long left = n - g0;
+  const int ng = left < gpw ? static_cast<int>(left) : gpw;
+  const int elems = ng * A * K;
+  const T* src = logits + g0 * A * K;
+  // stage: 4 elements per lane per iteration when the row group is 4-element aligned, else scalar
+  if (((A * K) & 3) == 0) {
+    for (int e = lane * 4; e < elems; e += 256) {
+      if constexpr (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + e);
+        buf[e] = v.x; buf[e + 1] = v.y; buf[e + 2] = v.z; buf[e + 3] = v.w;
+      } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(src + e);
+        const T* t = reinterpret_cast<const T*>(&raw);
+        buf[e] = to_f32<T>(t[0]); buf[e + 1] = to_f32<T>(t[1]); buf[e + 2] = to_f32<T>(t[2]); buf[e + 3] = to_f32<T>(t[3]);
+      }
+    }
+  } else {
+    for (int e = lane; e < elems; e += 64) buf[e] = to_f32<T>(src[e]);
+  }
+  hb::wave_sync();
+  const int gw = lane / A, a = lane - gw * A;
+  const bool on = gw < ng;
+  float q = -INFINITY;
+  bool is_legal = false;
+  if (on) {
+    const float* row = buf + (gw * A + a) * K;
+    float m = row[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, row[k]);
+    float s = 0.f, t = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float e = __expf(row[k] - m);
+      s += e;
+      t += e * support[k];
+    }
+    const float qv = t / s / static_cast<float>(K);
+    if (q_out) q_out[(g0 + gw) * A + a] = qv;
+    is_legal = legal[(g0 + gw) * A + a] != 0;
+    q = is_legal ? qv : -INFINITY;
+  }
+  qbuf[lane] = q;
+  hb::wave_sync();
+  if (on && a == 0) {
+    const float* qs = qbuf + gw * A;
+    float best = -INFINITY;
+    unsigned long long legal_mask = 0;
+    for (int i = 0; i < A; ++i) {
+      const float v = qs[i];
+      // -inf marks illegal moves; a legal move has a finite q
+      if (v > -INFINITY || legal[(g0 + gw) * A + i] != 0) legal_mask |= 1ull << i;
+      best = fmaxf(best, v);
+    }
+    unsigned long long ties = 0;
+    for (int i = 0; i < A; ++i)
+      if (((legal_mask >> i) & 1ull) && qs[i] == best) ties |= 1ull << i;
+    const unsigned long long gid = static_cast<unsigned long long>(first_gid + g0 + gw);
+    uint32_t r[4];
+    hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),
+                      static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+    const float u = static_cast<float>(r[0] >> 8) * (1.0f / 16777216.0f);
+    unsigned long long pool = (u < epsilon) ? legal_mask : ties;
+    if (pool == 0) pool = legal_mask;
+    int pick = 0;
+    const int c = __popcll(pool);
+    if (c > 0) {
+      int k = static_cast<int>(__umulhi(r[1], static_cast<uint32_t>(c)));
+      while (k-- > 0) pool &= pool - 1;
+      pick = __ffsll(static_cast<long long>(pool)) - 1;
+    }
+    actions[g0 + gw] = pick;
+  }
+}
+
+template <typename T>
+int launch_policy(const void* logits, const int8_t* legal, const float* support, int64_t n, int A, int K, float eps,
+                  uint64_t seed, uint64_t draw, int64_t first_gid, int32_t* actions, float* q_out, hipStream_t s) {
+  const int gpw = 64 / A;
+  const long long per_block = 4LL * gpw;
+  const unsigned blocks = static_cast<unsigned>((n + per_block - 1) / per_block);
+  const size_t lds = 4 * (static_cast<size_t>(gpw) * A * K + 64) * sizeof(float);
+  hipLaunchKernelGGL((policy_kernel<T>), dim3(blocks), dim3(256), lds, s, static_cast<const T*>(logits), legal, support,
+                     static_cast<long long>(n), A, K, eps, static_cast<unsigned long long>(seed),
+                     static_cast<unsigned long long>(draw), static_cast<long long>(first_gid), actions, q_out);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// replay insert: the acting seat's N transitions -> ring slots (start + i) mod cap, one launch
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+
+// copies `bytes` (16 bytes per lane, tail bytewise) to up to two destinations; rows are obs_len bytes apart, so
+// neither side is more than byte-aligned after a ring wrap: unaligned dwordx4 accesses (one instruction on gfx950)
+__device__ __forceinline__ void copy2(const int8_t* __restrict__ src, int8_t* __restrict__ d0, int8_t* __restrict__ d1,
+                                      long long bytes, long long tid, long long nthreads) {
+  const long long vec = bytes >> 4;
+  for (long long i = tid; i < vec; i += nthreads) {
+    const u32x4 v = *reinterpret_cast<const u32x4_u*>(src + (i << 4));
+    if (d0) *reinterpret_cast<u32x4_u*>(d0 + (i << 4)) = v;
+    if (d1) *reinterpret_cast<u32x4_u*>(d1 + (i << 4)) = v;
+  }
+  for (long long b = (vec << 4) + tid; b < bytes; b += nthreads) {
+    const int8_t v = src[b];
+    if (d0) d0[b] = v;
+    if (d1) d1[b] = v;
+  }
+}
+
+struct InsertArgs {
+  int8_t* last_obs;          // [n, L] in/out
+  const int8_t* obs;         // [n, L]
+  const int8_t* legal;       // [n, A]
+  const int32_t* actions;    // [n]
+  const float* rewards;      // [n]
+  const int8_t* step_type;   // [n]
+  int8_t* ring_obs_tm1;      // [cap, L]
+  int8_t* ring_obs_t;        // [cap, L]
+  int8_t* ring_act;          // [cap]
+  int8_t* ring_lms;          // [cap, A]
+  float* ring_rew;           // [cap]
+  uint8_t* ring_term;        // [cap] (bool)
+  long long n, cap, start;
+  int L, A;
+};
+
+// segment s (0 or 1) of the wrapped range: rows [row0, row0+rows) -> slots [slot0, slot0+rows)
+__global__ __launch_bounds__(256) void replay_insert_kernel(const InsertArgs a) {
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
+  const long long first = a.cap - a.start < a.n ? a.cap - a.start : a.n;  // rows before the wrap
+  for (int seg = 0; seg < 2; ++seg) {
+    const long long row0 = seg == 0 ? 0 : first;
+    const long long rows = seg == 0 ? first : a.n - first;
+    const long long slot0 = seg == 0 ? a.start : 0;
+    if (rows <= 0) continue;
+    // old last_obs -> ring.obs_tm1 ; new obs -> ring.obs_t and last_obs ; legal -> ring.lms
+    copy2(a.last_obs + row0 * a.L, a.ring_obs_tm1 + slot0 * a.L, nullptr, rows * a.L, tid, nthreads);
+    copy2(a.legal + row0 * a.A, a.ring_lms + slot0 * a.A, nullptr, rows * a.A, tid, nthreads);
+    for (long long i = tid; i < rows; i += nthreads) {
+      a.ring_act[slot0 + i] = static_cast<int8_t>(a.actions[row0 + i]);
+      a.ring_rew[slot0 + i] = a.rewards[row0 + i];
+      a.ring_term[slot0 + i] = a.step_type[row0 + i] == 2;
+    }
+  }
+}
+// second launch (after the first has consumed last_obs): obs -> ring.obs_t and last_obs
+__global__ __launch_bounds__(256) void replay_insert_obs_kernel(const InsertArgs a) {
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
+  const long long first = a.cap - a.start < a.n ? a.cap - a.start : a.n;
+  for (int seg = 0; seg < 2; ++seg) {
+    const long long row0 = seg == 0 ? 0 : first;
+    const long long rows = seg == 0 ? first : a.n - first;
+    const long long slot0 = seg == 0 ? a.start : 0;
+    if (rows <= 0) continue;
+    copy2(a.obs + row0 * a.L, a.ring_obs_t + slot0 * a.L, a.last_obs + row0 * a.L, rows * a.L, tid, nthreads);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* legal_dev, const float* support_dev,
+                  int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,
+                  int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream) {
+  if (!logits_dev || !legal_dev || !support_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
+  if (n_atoms < 1 || (64 / n_actions) * n_actions * n_atoms > MAX_WAVE_ELEMS)
+    return fail(HB_ERR_INVALID, "n_actions * n_atoms too large for the LDS staging buffer");
+  if (n_games <= 0) return HB_OK;
+  const int esz = logits_dtype == 0 ? 4 : 2;
+  if (reinterpret_cast<uintptr_t>(logits_dev) & (4 * esz - 1)) return fail(HB_ERR_ALIGN, "logits_dev must be 16-byte (fp32) / 8-byte (16-bit) aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (logits_dtype) {
+    case 0: return launch_policy<float>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+    case 1: return launch_policy<__hip_bfloat16>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+    case 2: return launch_policy<__half>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+  }
+  return fail(HB_ERR_INVALID, "logits_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+}
+
+int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* legal_dev, const int32_t* actions_dev,
+                     const float* rewards_dev, const int8_t* step_type_dev, int8_t* ring_obs_tm1_dev,
+                     int8_t* ring_obs_t_dev, int8_t* ring_act_dev, int8_t* ring_lms_dev, float* ring_rew_dev,
+                     uint8_t* ring_term_dev, int64_t n, int32_t obs_len, int32_t n_actions, int64_t capacity,
+                     int64_t start, void* stream) {
+  if (!last_obs_dev || !obs_dev || !legal_dev || !actions_dev || !rewards_dev || !step_type_dev || !ring_obs_tm1_dev ||
+      !ring_obs_t_dev || !ring_act_dev || !ring_lms_dev || !ring_rew_dev || !ring_term_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (n <= 0) return HB_OK;
+  if (n > capacity || start < 0 || start >= capacity) return fail(HB_ERR_INVALID, "bad ring range");
+  InsertArgs a{last_obs_dev, obs_dev, legal_dev, actions_dev, rewards_dev, step_type_dev, ring_obs_tm1_dev, ring_obs_t_dev,
+               ring_act_dev, ring_lms_dev, ring_rew_dev, ring_term_dev, n, capacity, start, obs_len, n_actions};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long vec = (n * obs_len) >> 4;
+  unsigned blocks = static_cast<unsigned>((vec + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(replay_insert_kernel, dim3(blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(replay_insert_obs_kernel, dim3(blocks), dim3(256), 0, s, a);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+}  // extern "C"

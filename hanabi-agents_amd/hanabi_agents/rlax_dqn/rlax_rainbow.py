@@ -158,6 +158,11 @@ class DQNAgent:
         self.requires_vectorized_observation = lambda: True
         self._gen = torch.Generator(device=self.device).manual_seed(params.seed + 1)
         self.last_loss = None
+        # fused HIP actor tail / replay insert (hanabi_hip.ops) on the GPU; plain torch ops elsewhere
+        self._fused = self.device.type == "cuda" and self.distributional
+        self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
+        self._draws = 0             # Philox draw counter of the fused sampler
+        self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _unpack(self, observations) -> Tuple[torch.Tensor, torch.Tensor, bool]:
@@ -178,10 +183,39 @@ class DQNAgent:
     def _net_input(self, obs):
         return obs.to(torch.float32)
 
+    def _effective_weights(self):
+        """[(W [in,out], bias [out])] of the online net in the GEMM dtype; recomputed only after the weights
+        or the noise changed (the reference's noise is frozen, App. C-2, so acting re-uses them all the time)."""
+        if self._eff_cache is None:
+            cd = _DTYPES[self.params.compute_dtype]
+            self._eff_cache = [tuple(t.to(cd).contiguous() for t in layer.effective()) for layer in self.online.layers]
+        return self._eff_cache
+
+    def _act_fused(self, obs, legal, epsilon):
+        """Actor on the GPU: int8 obs -> GEMM dtype, two bias-fused MFMA GEMMs, then ONE kernel for
+        softmax-expectation + legal mask + epsilon-greedy sample (hb_policy_act)."""
+        from hanabi_hip import ops
+
+        if self.params.resample_noise:
+            self.online.resample()
+            self._eff_cache = None
+        eff = self._effective_weights()
+        x = obs.to(eff[0][0].dtype)
+        for i, (w, b) in enumerate(eff):
+            x = torch.addmm(b, x, w)
+            if i < len(eff) - 1:
+                x = torch.relu_(x)
+        self._draws += 1
+        return ops.policy_act(x, legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
+                              self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
+
     # ---- acting (rlax_rainbow.py:277-290) ---------------------------------------------------------------
     @torch.no_grad()
     def exploit(self, observations):
         obs, legal, on_device = self._unpack(observations)
+        if self._fused:
+            actions = self._act_fused(obs, legal, 0.0)
+            return actions if on_device else actions.cpu().numpy()
         if self.params.resample_noise:
             self.online.resample()
         actions = DQNPolicy.eval_policy(self.online, self.atoms, self._net_input(obs), legal, self._uniform(obs.shape[0]),
@@ -191,6 +225,9 @@ class DQNAgent:
     @torch.no_grad()
     def explore(self, observations):
         obs, legal, on_device = self._unpack(observations)
+        if self._fused:
+            actions = self._act_fused(obs, legal, float(self.params.epsilon(self.train_step)))
+            return actions if on_device else actions.cpu().numpy()
         if self.params.resample_noise:
             self.online.resample()
         n = obs.shape[0]
@@ -224,6 +261,18 @@ class DQNAgent:
         """add_experience for callers that guarantee no FIRST rows (lock-step self-play after the first
         round): every row is a transition, so nothing is compacted and no device->host sync happens."""
         obs, legal, _ = self._unpack(observations)
+        if self.device.type == "cuda":
+            from hanabi_hip import ops
+
+            buf, n = self.experience, obs.shape[0]
+            start = buf.oldest_entry
+            if self.params.use_priority:  # new leaves enter at max priority (priority_buffer.py:29-32)
+                buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
+            ops.replay_insert(self.last_obs, obs.to(torch.int8).contiguous(), legal.to(torch.int8).contiguous(),
+                              self._vec(actions, torch.int32).contiguous(), self._vec(rewards, torch.float32).contiguous(),
+                              self._vec(step_types, torch.int8).contiguous(), buf, start)
+            buf._advance(n)
+            return
         obs8 = obs.to(torch.int8)
         st = self._vec(step_types, torch.int64)
         self.experience.add_transitions(self.last_obs, self._vec(actions, torch.int64).reshape(-1, 1),
@@ -254,6 +303,7 @@ class DQNAgent:
         loss.backward()
         self._allreduce_gradients()
         self.optimizer.step()
+        self._eff_cache = None
         self.last_loss = loss.detach()
         if self.params.use_priority:
             self.experience.update_priorities_dev(indices, new_prios)
@@ -291,5 +341,6 @@ class DQNAgent:
         torch.save(self.target.state_dict(), os.path.join(path, "rlax_rainbow_" + fname_part + "_target.pkl"))
 
     def restore_weights(self, online_weights_file, trg_weights_file):
+        self._eff_cache = None
         self.online.load_state_dict(torch.load(online_weights_file, map_location=self.device, weights_only=True))
         self.target.load_state_dict(torch.load(trg_weights_file, map_location=self.device, weights_only=True))

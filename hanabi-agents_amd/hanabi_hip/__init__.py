@@ -9,8 +9,9 @@ Public names: `HanabiEnv`, `SumTree`, `make_config`, `HbConfig`, `lib`, flag con
 """
 from ._capi import (FLAG_AUTO_RESET, FLAG_LENIENT_REWARD, FLAG_RESET_START_NEXT, GAME_TYPES, HbConfig, HbError,
                     lib, library_path, make_config)
+from . import ops
 from .env import HanabiEnv
 from .tree import SumTree
 
-__all__ = ["HanabiEnv", "SumTree", "make_config", "HbConfig", "HbError", "lib", "library_path", "GAME_TYPES",
+__all__ = ["ops", "HanabiEnv", "SumTree", "make_config", "HbConfig", "HbError", "lib", "library_path", "GAME_TYPES",
            "FLAG_AUTO_RESET", "FLAG_RESET_START_NEXT", "FLAG_LENIENT_REWARD"]

@@ -200,6 +200,29 @@ int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int64_t* idx_d
 int hb_per_update(hb_tree* t, const int64_t* idx_dev, const float* td_dev, int64_t n, double alpha,
                   float* max_prio_dev, float* min_prio_dev, void* stream);
 
+/* ---- fused actor tail (hanabi_agents/rlax_dqn/rlax_rainbow.py:113-122,141-150) ---------
+ * One pass over the C51 logits [n, n_actions * n_atoms] (logits_dtype 0 = f32, 1 = bf16,
+ * 2 = f16): q = mean(softmax(logits) * support, -1), illegal moves -> -inf, then the legal
+ * epsilon-greedy sample (epsilon = 0: greedy with uniform tie-breaking). Randomness is
+ * Philox4x32-10(seed; draw, first_game_id + g): word 0 -> explore decision, word 1 -> which
+ * candidate. support_dev [n_atoms] f32; actions_dev [n] int32; q_dev [n, n_actions] f32 or
+ * NULL (receives the UNMASKED q).                                                        */
+int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* legal_dev, const float* support_dev,
+                  int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,
+                  int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream);
+
+/* ---- fused replay insert (hanabi_agents/rlax_dqn/rlax_rainbow.py:297-308 +
+ *      experience_buffer.py:26-81 for a batch without FIRST rows) --------------------------
+ * Row i of the batch goes to ring slot (start + i) mod capacity:
+ *   ring_obs_tm1 <- last_obs, ring_obs_t <- obs, ring_lms <- legal, ring_act <- actions,
+ *   ring_rew <- rewards, ring_term <- (step_type == 2); then last_obs <- obs.
+ * The caller advances its ring pointer (experience_buffer.py:58-61,79-81).                */
+int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* legal_dev, const int32_t* actions_dev,
+                     const float* rewards_dev, const int8_t* step_type_dev, int8_t* ring_obs_tm1_dev,
+                     int8_t* ring_obs_t_dev, int8_t* ring_act_dev, int8_t* ring_lms_dev, float* ring_rew_dev,
+                     uint8_t* ring_term_dev, int64_t n, int32_t obs_len, int32_t n_actions, int64_t capacity,
+                     int64_t start, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""GPU: fused actor tail (hb_policy_act) and fused replay insert (hb_replay_insert) against plain
+PyTorch fp32 references of the same ops (DQNPolicy.q_values / DQNPolicy.sample, ExperienceBuffer.add_transitions)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,a,k", [(1000, 20, 51), (257, 48, 51), (64, 11, 51), (3, 20, 51), (500, 30, 7)])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_policy_q_values_and_greedy_choice(n, a, k, dtype):
+    import torch
+
+    from hanabi_agents.rlax_dqn import learning as L
+    from hanabi_hip import ops
+
+    g = torch.Generator(device="cuda").manual_seed(n + a)
+    dt = getattr(torch, dtype)
+    logits = (torch.randn(n, a * k, device="cuda", generator=g) * 2).to(dt)
+    legal = (torch.rand(n, a, device="cuda", generator=g) < 0.6).to(torch.int8)
+    legal[:, 0] = 1
+    support = torch.linspace(-25, 25, k, device="cuda")
+    q = torch.empty(n, a, device="cuda")
+    act = ops.policy_act(logits, legal, support, 0.0, seed=7, draw=3, q_out=q)
+    ref = L.expected_q(logits.float().view(n, a, k), support.repeat(a, 1))       # torch fp32 reference on the same inputs
+    assert torch.allclose(q, ref, rtol=2e-5, atol=2e-6)
+    masked = torch.where(legal.bool(), q, torch.full_like(q, float("-inf")))
+    # greedy: the chosen move is legal and attains the maximum of the kernel's own q
+    chosen = masked.gather(1, act.long()[:, None])[:, 0]
+    assert torch.equal(chosen, masked.max(dim=1).values)
+    assert bool(legal.gather(1, act.long()[:, None]).all())
+
+
+def test_policy_epsilon_greedy_distribution_and_ties():
+    import torch
+
+    from hanabi_hip import ops
+
+    n, a, k = 60000, 4, 5
+    logits = torch.zeros(n, a * k, device="cuda")
+    logits[:, 1 * k + 4] = 3.0   # action 1 and 2 tie for the best q, action 3 illegal
+    logits[:, 2 * k + 4] = 3.0
+    legal = torch.tensor([1, 1, 1, 0], dtype=torch.int8, device="cuda").repeat(n, 1).contiguous()
+    support = torch.linspace(-2, 2, k, device="cuda")
+    act = ops.policy_act(logits, legal, support, 0.3, seed=11, draw=1)
+    freq = torch.bincount(act.long(), minlength=a).double().cpu() / n
+    want = torch.tensor([0.1, 0.45, 0.45, 0.0], dtype=torch.float64)     # (1-eps)*[0,.5,.5,0] + eps*[1/3,1/3,1/3,0]
+    assert torch.allclose(freq, want, atol=0.01)
+    # deterministic given (seed, draw, game id); different draw -> different sample
+    again = ops.policy_act(logits, legal, support, 0.3, seed=11, draw=1)
+    other = ops.policy_act(logits, legal, support, 0.3, seed=11, draw=2)
+    assert torch.equal(act, again) and not torch.equal(act, other)
+    shifted = ops.policy_act(logits[:100], legal[:100], support, 0.3, seed=11, draw=1, first_game_id=50)
+    assert torch.equal(shifted[:50], act[50:100])                           # keyed by GLOBAL game id
+
+
+def test_agent_fused_explore_agrees_with_torch_policy():
+    """DQNAgent on cuda (fused path, fp32 GEMMs) picks the arg-max of the torch-op q wherever the top-2 gap is clear."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, DQNPolicy, ObservationSpec, RlaxRainbowParams
+
+    n, obs_len, n_act = 512, 658, 20
+    agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act),
+                     RlaxRainbowParams(experience_buffer_size=1024, epsilon=0.0), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    obs = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.7).to(torch.int8)
+    legal[:, 5] = 1
+    act = agent.exploit((None, (obs, legal)))
+    q = DQNPolicy.q_values(agent.online, agent.atoms, obs.float(), legal)
+    top2 = q.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert clear.sum() > n // 2
+    assert torch.equal(act[clear].long(), q.argmax(1)[clear])
+    assert bool(legal.gather(1, act.long()[:, None]).all())
+    # numpy in -> numpy out, like the reference
+    out = agent.explore((None, (obs.cpu().numpy(), legal.cpu().numpy())))
+    assert isinstance(out, np.ndarray) and out.shape == (n,)
+
+
+@pytest.mark.parametrize("cap,n,rounds", [(1000, 96, 25), (64, 64, 3), (4096, 1000, 9)])
+def test_fused_replay_insert_matches_torch_ring(cap, n, rounds):
+    import torch
+
+    from hanabi_agents.rlax_dqn.experience_buffer import ExperienceBuffer
+    from hanabi_hip import ops
+
+    obs_len, n_act = 658, 20
+    fused = ExperienceBuffer(obs_len, n_act, 1, cap, device="cuda")
+    plain = ExperienceBuffer(obs_len, n_act, 1, cap, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(cap)
+    last = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.5).to(torch.int8)
+    last_ref = last.clone()
+    for r in range(rounds):
+        obs = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.5).to(torch.int8)
+        legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.5).to(torch.int8)
+        act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+        rew = torch.randint(-3, 4, (n,), device="cuda", generator=g).float()
+        st = torch.randint(1, 3, (n,), device="cuda", generator=g).to(torch.int8)
+        ops.replay_insert(last, obs, legal, act, rew, st, fused, fused.oldest_entry)
+        fused._advance(n)
+        plain.add_transitions(last_ref, act.reshape(-1, 1), rew.reshape(-1, 1), obs, legal, (st == 2).reshape(-1, 1))
+        last_ref = obs.clone()
+        assert torch.equal(last, last_ref)
+        assert (fused.oldest_entry, fused.size) == (plain.oldest_entry, plain.size)
+    for name in ("_obs_tm1_buf", "_obs_t_buf", "_act_tm1_buf", "_lms_t_buf", "_rew_t_buf", "_terminal_t_buf"):
+        assert torch.equal(getattr(fused, name), getattr(plain, name)), name
