@@ -41,6 +41,7 @@ class ExperienceBuffer:
         self.capacity = capacity
         self.size = 0
         self._gen = torch.Generator(device=d).manual_seed(seed)
+        self._size_t = torch.zeros((), dtype=torch.float64, device=d)
 
     # ---- ring arithmetic (experience_buffer.py:21-24,46-81) ---------------------------------------
     def get_update_indices(self, batch_size):
@@ -107,7 +108,16 @@ class ExperienceBuffer:
         """Uniform WITH replacement over [0, size) (experience_buffer.py:96; C-11), own generator."""
         if self.size == 0:
             raise ValueError("cannot sample from an empty buffer")
+        if self.device.type == "cuda":
+            # graph-safe form: default generator + a device-side copy of `size` (refreshed by sync_size() outside
+            # any captured region), so a captured update keeps sampling from the ring as it fills
+            u = torch.rand(batch_size, device=self.device, dtype=torch.float64)
+            return torch.minimum((u * self._size_t).long(), (self._size_t - 1).long())
         return torch.randint(0, self.size, (batch_size,), device=self.device, generator=self._gen)
+
+    def sync_size(self):
+        """Publish the host-side `size` to the device scalar used by sample_indices_dev."""
+        self._size_t.fill_(float(self.size))
 
     def sample_dev(self, batch_size: int) -> Transition:
         return self.gather_dev(self.sample_indices_dev(batch_size))

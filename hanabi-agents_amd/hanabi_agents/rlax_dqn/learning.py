@@ -62,8 +62,8 @@ def categorical_double_q_td(logits_tm1, a_tm1, r_t, discount, atoms, logits_t, l
     return -torch.sum(target * logp, dim=-1)
 
 
-def is_weights(prios: torch.Tensor, beta: float) -> torch.Tensor:
-    """(1/P)^beta normalised by its max, float32 (rlax_rainbow.py:188-189; App. C-6)."""
+def is_weights(prios: torch.Tensor, beta) -> torch.Tensor:
+    """(1/P)^beta normalised by its max, float32 (rlax_rainbow.py:188-189; App. C-6). beta: float or 0-d tensor."""
     w = (1.0 / prios).to(torch.float32) ** beta
     return w / torch.max(w)
 

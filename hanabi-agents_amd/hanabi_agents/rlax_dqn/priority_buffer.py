@@ -48,7 +48,8 @@ class PriorityBuffer(ExperienceBuffer):
         """(indices int64 [B], probabilities float64 [B], Transition of device tensors).
         uniforms: optional float64 [B] in [0, 1/B) (parity tests); otherwise drawn on the device."""
         if uniforms is None:
-            uniforms = torch.rand(batch_size, dtype=torch.float64, device=self.device, generator=self._gen) / batch_size
+            # default device generator: its Philox offset is graph-safe, so the draw can live inside a captured update
+            uniforms = torch.rand(batch_size, dtype=torch.float64, device=self.device) / batch_size
         else:
             uniforms = _dev(uniforms, self.device, torch.float64)
         indices, prios = self.sum_tree.per_sample_dev(uniforms)
