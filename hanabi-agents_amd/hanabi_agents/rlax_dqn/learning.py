@@ -53,7 +53,7 @@ def categorical_double_q_td(logits_tm1, a_tm1, r_t, discount, atoms, logits_t, l
     q_sel = expected_q(logits_sel, atoms)                        # no legal-move mask, as in the reference
     a_star = torch.argmax(q_sel, dim=-1)
     p_target = F.softmax(logits_t[ar, a_star], dim=-1)           # [B, K]
-    disc = torch.as_tensor(discount, dtype=r_t.dtype, device=r_t.device).expand(b)
+    disc = torch.full((b,), float(discount), dtype=r_t.dtype, device=r_t.device)  # (a fill kernel: graph-capturable)
     if terminal_t is not None:
         disc = disc * (1.0 - terminal_t.to(r_t.dtype))
     target_z = r_t[:, None] + disc[:, None] * support[None, :]

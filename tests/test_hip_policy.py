@@ -115,7 +115,7 @@ def test_graphed_update_equals_eager_update():
     from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
 
     n, obs_len, n_act = 256, 658, 20
-    params = RlaxRainbowParams(use_priority=False, train_batch_size=256, experience_buffer_size=256, target_update_period=3)
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=256, experience_buffer_size=256, target_update_period=4)
     agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=g) for g in (True, False)]
     g = torch.Generator(device="cuda").manual_seed(1)
     o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
@@ -127,9 +127,9 @@ def test_graphed_update_equals_eager_update():
         a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
         a.add_experience((None, (o2, legal)), act, rew, torch.ones(n, dtype=torch.int8, device="cuda"))
         a.experience.sample_indices_dev = lambda b: torch.arange(b, device="cuda")   # same batch, fixed order
-    for _ in range(3):       # the graphed agent spends 3 warm-up updates at capture time: give the eager one the same
-        agents[1].update()
-    agents[1].train_step -= 3
+    for _ in range(3):       # the graphed agent spends 3 warm-up updates (no target sync) at capture time: same here
+        agents[1].experience.sync_size()
+        agents[1]._update_eager()
     for step in range(6):
         for a in agents:
             a.update()
