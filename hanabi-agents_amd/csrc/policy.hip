@@ -53,17 +53,28 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
   const int ng = left < gpw ? static_cast<int>(left) : gpw;
   const int elems = ng * A * K;
   const T* src = logits + g0 * A * K;
-  // stage: 4 elements per lane per iteration when the row group is 4-element aligned, else scalar
+  // stage HBM -> LDS: 4 elements per lane per load, FOUR independent loads in flight per lane before the first
+  // LDS write (a wave owns ~12 KB of logits; issuing the loads back-to-back hides the HBM latency once, not 12x)
   if (((A * K) & 3) == 0) {
-    for (int e = lane * 4; e < elems; e += 256) {
-      if constexpr (sizeof(T) == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + e);
-        buf[e] = v.x; buf[e + 1] = v.y; buf[e + 2] = v.z; buf[e + 3] = v.w;
-      } else {
-        const uint2 raw = *reinterpret_cast<const uint2*>(src + e);
-        const T* t = reinterpret_cast<const T*>(&raw);
-        buf[e] = to_f32<T>(t[0]); buf[e + 1] = to_f32<T>(t[1]); buf[e + 2] = to_f32<T>(t[2]); buf[e + 3] = to_f32<T>(t[3]);
+    for (int base = 0; base < elems; base += 1024) {
+      int e[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e[u] = base + u * 256 + lane * 4;
+        if (e[u] < elems) {
+          if constexpr (sizeof(T) == 4) {
+            v[u] = *reinterpret_cast<const float4*>(src + e[u]);
+          } else {
+            const uint2 raw = *reinterpret_cast<const uint2*>(src + e[u]);
+            const T* t = reinterpret_cast<const T*>(&raw);
+            v[u] = make_float4(to_f32<T>(t[0]), to_f32<T>(t[1]), to_f32<T>(t[2]), to_f32<T>(t[3]));
+          }
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e[u] < elems) { buf[e[u]] = v[u].x; buf[e[u] + 1] = v[u].y; buf[e[u] + 2] = v[u].z; buf[e[u] + 3] = v[u].w; }
     }
   } else {
     for (int e = lane; e < elems; e += 64) buf[e] = to_f32<T>(src[e]);
@@ -209,9 +220,47 @@ __global__ __launch_bounds__(256) void replay_insert_obs_kernel(const InsertArgs
   }
 }
 
+// int8 0/1 observations -> bf16 / f16 GEMM operand: 16 bytes in, 32 bytes out per lane
+template <typename T>
+__global__ __launch_bounds__(256) void obs_cast_kernel(const int8_t* __restrict__ in, T* __restrict__ out, long long n) {
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
+  const long long vec = n >> 4;
+  for (long long i = tid; i < vec; i += nthreads) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(in + (i << 4));
+    const int8_t* b = reinterpret_cast<const int8_t*>(&raw);
+    T o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = static_cast<T>(static_cast<float>(b[j]));
+    uint4* dst = reinterpret_cast<uint4*>(out + (i << 4));
+    dst[0] = *reinterpret_cast<const uint4*>(o);
+    dst[1] = *reinterpret_cast<const uint4*>(o + 8);
+  }
+  for (long long j = (vec << 4) + tid; j < n; j += nthreads) out[j] = static_cast<T>(static_cast<float>(in[j]));
+}
+
 }  // namespace
 
 extern "C" {
+
+int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t n_elements, void* stream) {
+  if (!obs_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_elements <= 0) return HB_OK;
+  if ((reinterpret_cast<uintptr_t>(obs_dev) & 15) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
+    return fail(HB_ERR_ALIGN, "obs_dev / out_dev must be 16-byte aligned");
+  long long blocks = ((n_elements >> 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_dtype == 1)
+    hipLaunchKernelGGL((obs_cast_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__hip_bfloat16*>(out_dev), static_cast<long long>(n_elements));
+  else if (out_dtype == 2)
+    hipLaunchKernelGGL((obs_cast_kernel<__half>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__half*>(out_dev), static_cast<long long>(n_elements));
+  else
+    return fail(HB_ERR_INVALID, "out_dtype must be 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
 
 int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* legal_dev, const float* support_dev,
                   int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,

@@ -173,6 +173,7 @@ class DQNAgent:
         # fused HIP actor tail / replay insert (hanabi_hip.ops) on the GPU; plain torch ops elsewhere
         self._fused = self.device.type == "cuda" and self.distributional
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
+        self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
 
@@ -212,7 +213,8 @@ class DQNAgent:
             self.online.resample()
             self._eff_cache = None
         eff = self._effective_weights()
-        x = obs.to(eff[0][0].dtype)
+        cd = eff[0][0].dtype
+        x = ops.obs_cast(obs.contiguous(), cd) if (obs.dtype == torch.int8 and cd != torch.float32) else obs.to(cd)
         for i, (w, b) in enumerate(eff):
             x = torch.addmm(b, x, w)
             if i < len(eff) - 1:
@@ -310,8 +312,25 @@ class DQNAgent:
             self._update_eager()
         self._eff_cache = None
         if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
-            self.target.load_state_dict(self.online.state_dict())
+            self._sync_target()
         self.train_step += 1
+
+    def _sync_target(self):
+        with torch.no_grad():
+            for dst, src in zip(list(self.target.parameters()) + list(self.target.buffers()),
+                                list(self.online.parameters()) + list(self.online.buffers())):
+                dst.copy_(src)
+        self._refresh_target_cache()
+
+    def _refresh_target_cache(self):
+        if self._trg_cache is None:
+            return
+        with torch.no_grad():  # IN PLACE: captured graphs hold these tensors
+            cd = _DTYPES[self.params.compute_dtype]
+            for (w_c, b_c), layer in zip(self._trg_cache, self.target.layers):
+                w, bias = layer.effective()
+                w_c.copy_(w.to(cd))
+                b_c.copy_(bias.to(cd))
 
     # The update is split where the (optional) collective sits:
     #   part 1: PER sample -> gather -> 3 forwards -> loss -> backward into ONE flat gradient buffer
@@ -319,14 +338,59 @@ class DQNAgent:
     #   part 2: Adam step -> priority update
     # Eagerly that is ~120 kernel launches (host-bound at ~1.7 ms on the MI355X box); on the GPU each part
     # is captured once into a HIP graph and replayed with a single launch.
+    def _target_weights(self):
+        """Effective weights of the TARGET net in the GEMM dtype; they only change when the target is synced."""
+        if self._trg_cache is None:
+            cd = _DTYPES[self.params.compute_dtype]
+            with torch.no_grad():
+                self._trg_cache = [tuple(t.to(cd).contiguous() for t in layer.effective()) for layer in self.target.layers]
+        return self._trg_cache
+
+    def _loss_batched(self, tr, prios):
+        """Same arithmetic as DQNLearning.loss for the C51 net, arranged for the GPU: the two ONLINE forwards
+        (obs_tm1 with gradient, obs_t for action selection) run as one 2B-row pass over effective weights that
+        are formed once; the target pass re-uses cached effective weights; observations go int8 -> GEMM dtype
+        directly. Roughly 2.5x fewer kernels than three independent module forwards."""
+        cd = _DTYPES[self.params.compute_dtype]
+        b = tr.observation_tm1.shape[0]
+        x = torch.cat([tr.observation_tm1, tr.observation_t], dim=0).to(cd)
+        h = x
+        layers = self.online.layers
+        for i, layer in enumerate(layers):
+            w, bias = layer.effective()
+            h = torch.addmm(bias.to(cd), h, w.to(cd))
+            if i < len(layers) - 1:
+                h = torch.relu(h)
+        a, k = self.atoms.shape
+        logits_on = h.float().view(2 * b, a, k)
+        with torch.no_grad():
+            ht = x[b:]
+            trg = self._target_weights()
+            for i, (w, bias) in enumerate(trg):
+                ht = torch.addmm(bias, ht, w)
+                if i < len(trg) - 1:
+                    ht = torch.relu_(ht)
+            logits_t = ht.float().view(b, a, k)
+        term = tr.terminal_t[:, 0]
+        td = L.categorical_double_q_td(logits_on[:b], tr.action_tm1[:, 0].long(), tr.reward_t[:, 0].to(torch.float32),
+                                       self.params.discount, self.atoms, logits_t, logits_on[b:].detach(),
+                                       term if self.params.mask_terminal else None)
+        w_is = L.is_weights(prios, self._beta)
+        return torch.mean(td * w_is), torch.abs(td).detach()
+
     def _update_part1(self):
         indices, prios, tr = self._sample()
-        tr = tr._replace(observation_tm1=self._net_input(tr.observation_tm1), observation_t=self._net_input(tr.observation_t))
         if self.params.resample_noise:
             self.online.resample()
             self.target.resample()
-        loss, new_prios = DQNLearning.loss(self.online, self.target, self.atoms, tr, self.params.discount, prios,
-                                           self._beta, self.params.mask_terminal, self.distributional)
+            self._trg_cache = None
+        if self._fused:
+            loss, new_prios = self._loss_batched(tr, prios)
+        else:
+            tr = tr._replace(observation_tm1=self._net_input(tr.observation_tm1),
+                             observation_t=self._net_input(tr.observation_t))
+            loss, new_prios = DQNLearning.loss(self.online, self.target, self.atoms, tr, self.params.discount, prios,
+                                               self._beta, self.params.mask_terminal, self.distributional)
         self._flat_grad.zero_()
         loss.backward()  # every p.grad is a view into _flat_grad: gradients accumulate in place
         return loss.detach(), indices, new_prios
@@ -396,3 +460,4 @@ class DQNAgent:
         self._eff_cache = None
         self.online.load_state_dict(torch.load(online_weights_file, map_location=self.device, weights_only=True))
         self.target.load_state_dict(torch.load(trg_weights_file, map_location=self.device, weights_only=True))
+        self._refresh_target_cache()

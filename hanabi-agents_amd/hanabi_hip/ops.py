@@ -19,6 +19,14 @@ def policy_act(logits, legal, support, epsilon, seed, draw, first_game_id=0, act
     return actions
 
 
+def obs_cast(obs, dtype, out=None):
+    """int8 0/1 [N, L] -> bf16 / f16 tensor of the same shape (one HBM pass)."""
+    assert obs.dtype == torch.int8 and obs.is_cuda and obs.is_contiguous() and dtype in (torch.bfloat16, torch.float16)
+    out = out if out is not None else torch.empty(obs.shape, dtype=dtype, device=obs.device)
+    K.check(K.lib().hb_obs_cast(K.dptr(obs), K.dptr(out), _DT[dtype], obs.numel(), K.current_stream()))
+    return out
+
+
 def replay_insert(last_obs, obs, legal, actions, rewards, step_types, ring, start):
     """ring: object with _obs_tm1_buf, _obs_t_buf, _act_tm1_buf, _lms_t_buf, _rew_t_buf, _terminal_t_buf, capacity."""
     n, obs_len = obs.shape

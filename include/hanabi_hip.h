@@ -211,6 +211,10 @@ int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* le
                   int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,
                   int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream);
 
+/* int8 0/1 observation matrix -> 16-bit float GEMM operand (out_dtype 1 = bf16, 2 = f16),
+ * 16 bytes in / 32 bytes out per lane; both pointers 16-byte aligned.                     */
+int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t n_elements, void* stream);
+
 /* ---- fused replay insert (hanabi_agents/rlax_dqn/rlax_rainbow.py:297-308 +
  *      experience_buffer.py:26-81 for a batch without FIRST rows) --------------------------
  * Row i of the batch goes to ring slot (start + i) mod capacity:

@@ -137,3 +137,44 @@ def test_graphed_update_equals_eager_update():
     assert torch.allclose(w[0], w[1], rtol=1e-4, atol=1e-6)
     assert agents[0]._graph1 is not None and agents[1]._graph1 is None
     assert torch.allclose(agents[0].last_loss, agents[1].last_loss, rtol=1e-4)
+
+
+def test_batched_gpu_loss_equals_reference_loss_and_gradient():
+    """DQNAgent._loss_batched (one 2B-row online pass, cached target weights) vs DQNLearning.loss (three module
+    forwards) in fp32: same loss, same per-sample |td|, same gradient."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, DQNLearning, ObservationSpec, RlaxRainbowParams
+
+    n, obs_len, n_act = 256, 658, 20
+    for mask in (False, True):
+        agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act),
+                         RlaxRainbowParams(use_priority=False, experience_buffer_size=256, mask_terminal=mask), device="cuda",
+                         use_graphs=False)
+        with torch.no_grad():  # make target != online and biases non-zero
+            for p in agent.target.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
+            for layer in agent.online.layers:
+                layer.b_sigma.normal_(0, 0.1)
+                layer.b_mu.normal_(0, 0.1)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        from hanabi_agents.rlax_dqn.transition import Transition
+
+        tr = Transition((torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8),
+                        torch.randint(0, n_act, (n, 1), device="cuda", generator=g).to(torch.int8),
+                        torch.randint(-2, 3, (n, 1), device="cuda", generator=g).float(),
+                        (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8),
+                        torch.ones(n, n_act, dtype=torch.int8, device="cuda"),
+                        torch.rand(n, 1, device="cuda", generator=g) < 0.3)
+        prios = torch.rand(n, device="cuda", generator=g, dtype=torch.float64) + 0.01
+        agent._beta.fill_(0.4)
+        params = list(agent.online.parameters())
+        loss_a, td_a = agent._loss_batched(tr, prios)
+        grads_a = torch.autograd.grad(loss_a, params)
+        trf = tr._replace(observation_tm1=tr.observation_tm1.float(), observation_t=tr.observation_t.float())
+        loss_b, td_b = DQNLearning.loss(agent.online, agent.target, agent.atoms, trf, 0.99, prios, 0.4, mask)
+        grads_b = torch.autograd.grad(loss_b, params)
+        assert torch.allclose(loss_a, loss_b, rtol=1e-5)
+        assert torch.allclose(td_a, td_b, rtol=1e-4, atol=1e-5)
+        for ga, gb in zip(grads_a, grads_b):
+            assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-6)
