@@ -1,0 +1,269 @@
+// learner.hip — the non-GEMM parts of one learner update, fused for gfx950.
+//
+// DQNLearning.update_q of the reference (hanabi_agents/rlax_dqn/rlax_rainbow.py:152-217) is, apart from the
+// dense layers, a long chain of tiny elementwise / reduce ops on [B, A, K] = [256, 20, 51] tensors; as
+// separate launches they cost ~0.5 ms per update on the MI355X (launch-bound). Here they are three kernels:
+//
+//   replay_gather    indices -> X [2B, L] in the GEMM dtype (rows 0..B-1 = obs_tm1, B..2B-1 = obs_t) plus the
+//                    compact action / reward / terminal columns (experience_buffer.py:83-87 gather)
+//   c51_loss_grad    IS weights (rlax_rainbow.py:188-189), double-Q action selection on the online logits of
+//                    obs_t (:175-176), target distribution from the target net, Cramer/L2 projection onto the
+//                    support (rlax.categorical_l2_project), cross-entropy against the online
+//                    logits of obs_tm1 (:182-184), and d(mean(td*w))/d(logits_tm1) — one wavefront per sample
+//   noisy_adam       gradient of the merged weight W = w + w_mu + w_sigma*eps routed to the three parameters
+//                    (g, g, g*eps), optix/torch Adam (eps 3.125e-5 outside the sqrt, rlax_rainbow.py:257) on all
+//                    three, and the NEXT effective weight written in the GEMM dtype — so the forward never
+//                    re-forms effective weights and the actor re-uses them
+// The GEMMs between them stay in hipBLASLt (torch.addmm / torch.mm on MFMA).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/hanabi_hip.h"
+#include "common.hpp"
+
+using hb::fail;
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ld(const T* p, long long i);
+template <> __device__ __forceinline__ float ld<float>(const float* p, long long i) { return p[i]; }
+template <> __device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bfloat16* p, long long i) { return __bfloat162float(p[i]); }
+template <> __device__ __forceinline__ float ld<__half>(const __half* p, long long i) { return __half2float(p[i]); }
+template <typename T> __device__ __forceinline__ void st(T* p, long long i, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, long long i, float v) { p[i] = __float2bfloat16(v); }
+template <> __device__ __forceinline__ void st<__half>(__half* p, long long i, float v) { p[i] = __float2half(v); }
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(const int8_t* __restrict__ ring_tm1, const int8_t* __restrict__ ring_t,
+                                                     const int8_t* __restrict__ ring_act, const float* __restrict__ ring_rew,
+                                                     const uint8_t* __restrict__ ring_term, const int64_t* __restrict__ idx,
+                                                     int B, int L, T* __restrict__ x, int32_t* __restrict__ act,
+                                                     float* __restrict__ rew, float* __restrict__ term) {
+  const int r = blockIdx.x;  // output row 0..2B-1
+  const int b = r < B ? r : r - B;
+  const long long slot = idx[b];
+  const int8_t* src = (r < B ? ring_tm1 : ring_t) + slot * L;
+  T* dst = x + static_cast<long long>(r) * L;
+  for (int j = threadIdx.x; j < L; j += 256) st<T>(dst, j, static_cast<float>(src[j]));
+  if (r < B && threadIdx.x == 0) {
+    act[b] = ring_act[slot];
+    rew[b] = ring_rew[slot];
+    term[b] = ring_term[slot] ? 1.f : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one wavefront per sample; requires A <= 64 and K <= 64
+template <typename T>
+__global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_on, const T* __restrict__ logits_t,
+                                                  const int32_t* __restrict__ act, const float* __restrict__ rew,
+                                                  const float* __restrict__ term, const double* __restrict__ prios,
+                                                  const float* __restrict__ beta_dev, float discount, int mask_terminal,
+                                                  const float* __restrict__ support, int B, int A, int K,
+                                                  float* __restrict__ td_out, float* __restrict__ w_out,
+                                                  T* __restrict__ dlogits) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int AK = A * K;
+  float* sel = lds + wave * (AK + 64);
+  // ---- importance weight: ((1/P).astype(f32)) ** beta, normalised by its batch maximum (rlax_rainbow.py:188-189)
+  const float beta = *beta_dev;
+  float wmax = 0.f;
+  for (int j = lane; j < B; j += 64) wmax = fmaxf(wmax, powf(static_cast<float>(1.0 / prios[j]), beta));
+  wmax = wave_max(wmax);
+  const float w_b = powf(static_cast<float>(1.0 / prios[b]), beta) / wmax;
+  // ---- double-Q selector: q_sel[a] = mean(softmax(online(obs_t))[a] * z) (no legal mask, as the reference)
+  const T* row_sel = logits_on + static_cast<long long>(B + b) * AK;
+  for (int e = lane; e < AK; e += 64) sel[e] = ld<T>(row_sel, e);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float q = -INFINITY;
+  if (lane < A) {
+    const float* r = sel + lane * K;
+    float m = r[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, r[k]);
+    float s = 0.f, t = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float e = __expf(r[k] - m);
+      s += e;
+      t += e * support[k];
+    }
+    q = t / s / static_cast<float>(K);
+  }
+  const float qbest = wave_max(q);
+  const unsigned long long hit = __ballot(lane < A && q == qbest);
+  const int a_star = __ffsll(static_cast<long long>(hit)) - 1;  // lowest index among ties, like argmax
+  // ---- target distribution p = softmax(target(obs_t)[a*]) and its projection onto the support
+  const bool atom = lane < K;
+  const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * AK + a_star * K + lane) : -INFINITY;
+  const float mt = wave_max(lt);
+  const float et = atom ? __expf(lt - mt) : 0.f;
+  const float p = et / wave_sum(et);
+  const float vmin = support[0], vmax = support[K - 1];
+  const float delta = (vmax - vmin) / static_cast<float>(K - 1);
+  float gamma = discount;
+  if (mask_terminal) gamma *= 1.f - term[b];
+  const float zi = atom ? support[lane] : 0.f;
+  const float tz = fminf(fmaxf(rew[b] + gamma * zi, vmin), vmax);  // clipped r + gamma * z_j held by lane j
+  float target = 0.f;
+  for (int j = 0; j < K; ++j) {
+    const float pj = __shfl(p, j), tzj = __shfl(tz, j);
+    target += pj * fminf(fmaxf(1.f - fabsf(tzj - zi) / delta, 0.f), 1.f);
+  }
+  if (!atom) target = 0.f;
+  // ---- cross-entropy against log_softmax(online(obs_tm1)[a_tm1]) and its gradient
+  const int a_tm1 = act[b];
+  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * AK + a_tm1 * K + lane) : -INFINITY;
+  const float m1 = wave_max(l1);
+  const float e1 = atom ? __expf(l1 - m1) : 0.f;
+  const float s1 = wave_sum(e1);
+  const float logp = atom ? (l1 - m1 - __logf(s1)) : 0.f;
+  const float td = -wave_sum(target * logp);
+  const float tsum = wave_sum(target);
+  if (lane == 0) {
+    td_out[b] = td;
+    w_out[b] = w_b;
+  }
+  T* drow = dlogits + static_cast<long long>(b) * AK;
+  for (int e = lane; e < AK; e += 64) st<T>(drow, e, 0.f);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (atom) st<T>(drow, a_tm1 * K + lane, (w_b / static_cast<float>(B)) * (e1 / s1 * tsum - target));
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float *w, *w_mu, *w_sigma;
+  const float* noise;  // eps of the layer (same shape); bias noise for bias tensors
+  const float* grad;   // d loss / d (merged tensor), fp32
+  float *m_w, *v_w, *m_mu, *v_mu, *m_sg, *v_sg;
+  const float* step;   // number of completed Adam steps (device scalar)
+  void* eff;           // merged tensor in the GEMM dtype for the next forward
+  long long n;
+  float lr, b1, b2, eps;
+};
+
+__device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float b1, float b2, float bc1, float bc2s,
+                                       float lr, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  return p - (lr / bc1) * m / (sqrtf(v) / bc2s + eps);  // torch.optim.Adam / optix.adam: eps outside the sqrt
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
+  const float t = *a.step + 1.f;
+  const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
+  T* eff = static_cast<T*>(a.eff);
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const float g = a.grad[i], nz = a.noise[i];
+    float m, v;
+    m = a.m_w[i]; v = a.v_w[i];
+    const float w = adam1(a.w[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_w[i] = m; a.v_w[i] = v; a.w[i] = w;
+    m = a.m_mu[i]; v = a.v_mu[i];
+    const float mu = adam1(a.w_mu[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_mu[i] = m; a.v_mu[i] = v; a.w_mu[i] = mu;
+    m = a.m_sg[i]; v = a.v_sg[i];
+    const float sg = adam1(a.w_sigma[i], g * nz, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
+    st<T>(eff, i, w + mu + sg * nz);
+  }
+}
+
+template <typename T>
+void launch_adam(const AdamArgs& a, hipStream_t s) {
+  long long blocks = (a.n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((noisy_adam_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
+                     const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
+                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t* act_dev, float* rew_dev, float* term_dev,
+                     void* stream) {
+  if (!ring_obs_tm1_dev || !ring_obs_t_dev || !ring_act_dev || !ring_rew_dev || !ring_term_dev || !idx_dev || !x_dev ||
+      !act_dev || !rew_dev || !term_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (batch <= 0) return HB_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(2 * batch)), block(256);
+  const int B = static_cast<int>(batch);
+  if (x_dtype == 0)
+    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), act_dev, rew_dev, term_dev);
+  else if (x_dtype == 1)
+    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), act_dev, rew_dev, term_dev);
+  else if (x_dtype == 2)
+    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), act_dev, rew_dev, term_dev);
+  else
+    return fail(HB_ERR_INVALID, "x_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
+                     const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
+                     float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
+                     int32_t n_atoms, float* td_dev, float* w_dev, void* dlogits_dev, void* stream) {
+  if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev ||
+      !support_dev || !td_dev || !w_dev || !dlogits_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions < 1 || n_actions > 64 || n_atoms < 2 || n_atoms > 64) return fail(HB_ERR_INVALID, "need n_actions <= 64 and 2 <= n_atoms <= 64");
+  if (batch <= 0) return HB_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>((batch + 3) / 4)), block(256);
+  const size_t lds = 4 * (static_cast<size_t>(n_actions) * n_atoms + 64) * sizeof(float);
+  const int B = static_cast<int>(batch);
+#define HB_C51(T)                                                                                                       \
+  hipLaunchKernelGGL((c51_kernel<T>), grid, block, lds, s, static_cast<const T*>(logits_online_dev),                    \
+                     static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, discount, \
+                     mask_terminal, support_dev, B, n_actions, n_atoms, td_dev, w_dev, static_cast<T*>(dlogits_dev))
+  if (dtype == 0) HB_C51(float);
+  else if (dtype == 1) HB_C51(__hip_bfloat16);
+  else if (dtype == 2) HB_C51(__half);
+  else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+#undef HB_C51
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float* noise_dev, const float* grad_dev,
+                  float* m_w_dev, float* v_w_dev, float* m_mu_dev, float* v_mu_dev, float* m_sigma_dev, float* v_sigma_dev,
+                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, float lr, float beta1, float beta2,
+                  float eps, void* stream) {
+  if (!w_dev || !w_mu_dev || !w_sigma_dev || !noise_dev || !grad_dev || !m_w_dev || !v_w_dev || !m_mu_dev || !v_mu_dev ||
+      !m_sigma_dev || !v_sigma_dev || !step_dev || !eff_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (n <= 0) return HB_OK;
+  AdamArgs a{w_dev, w_mu_dev, w_sigma_dev, noise_dev, grad_dev, m_w_dev, v_w_dev, m_mu_dev, v_mu_dev, m_sigma_dev, v_sigma_dev,
+             step_dev, eff_dev, n, lr, beta1, beta2, eps};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eff_dtype == 0) launch_adam<float>(a, s);
+  else if (eff_dtype == 1) launch_adam<__hip_bfloat16>(a, s);
+  else if (eff_dtype == 2) launch_adam<__half>(a, s);
+  else return fail(HB_ERR_INVALID, "eff_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+}  // extern "C"

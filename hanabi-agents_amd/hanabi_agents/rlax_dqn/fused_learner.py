@@ -1,0 +1,135 @@
+"""FusedLearner — one learner update as ~30 launches instead of ~250 (GPU only).
+
+Same arithmetic as `DQNLearning.loss` + `torch.optim.Adam` on the NoisyMLP (the PyTorch-autograd
+path in rlax_rainbow.py stays as the fp32 reference and is what runs on the CPU), arranged as
+
+    PER sample (hb_per_sample)  ->  gather into the GEMM operand (hb_replay_gather)
+    ->  online pass on 2B rows + target pass on B rows: torch.addmm on MFMA, effective weights
+        W = w + w_mu + w_sigma*eps already materialised in the GEMM dtype
+    ->  hb_c51_loss_grad: IS weights, double-Q selection, projection, cross-entropy, dLoss/dlogits
+    ->  backward by hand: dW2 = H^T dlogits, dH = dlogits W2^T masked by ReLU, dW1 = X^T dH,
+        bias grads by column sums; all written into ONE flat fp32 gradient buffer
+    [-> one RCCL all-reduce of that buffer when data-parallel]
+    ->  hb_noisy_adam per merged tensor: routes the gradient to (w, w_mu, w_sigma) as (g, g, g*eps), Adam on
+        each, and emits the next effective weight
+    ->  priority update (hb_per_update)
+
+The reference computes the same thing through jax.grad of the loss (hanabi_agents/rlax_dqn/rlax_rainbow.py:
+152-217) with the six-parameter layer of noisy_mlp.py:61-91; since dW/dw = dW/dw_mu = 1 and dW/dw_sigma = eps,
+the hand-written backward is exact, not an approximation. Both halves (before / after the optional collective)
+are captured into HIP graphs by the agent.
+"""
+import torch
+
+from hanabi_hip import _capi as K
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class FusedLearner:
+    def __init__(self, agent):
+        self.agent = agent
+        p = agent.params
+        dev = agent.device
+        self.cd = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[p.compute_dtype]
+        self.B = p.train_batch_size
+        self.A, self.Kk = agent.atoms.shape
+        self.L = agent.obs_len
+        layers = agent.online.layers
+        assert len(layers) == 2, "the fused learner covers the reference topology: one hidden layer (params.layers=[H])"
+        self.layers = layers
+        B, AK = self.B, self.A * self.Kk
+        H = layers[0].out_features
+        f32 = dict(dtype=torch.float32, device=dev)
+        # merged tensors per layer: (weight, bias); effective values in the GEMM dtype
+        self.eff = [(torch.empty(l.in_features, l.out_features, dtype=self.cd, device=dev),
+                     torch.empty(l.out_features, dtype=self.cd, device=dev)) for l in layers]
+        self.trg = [(torch.empty_like(w), torch.empty_like(b)) for w, b in self.eff]
+        # flat gradient buffer [dW1 | db1 | dW2 | db2] (fp32), one all-reduce bucket
+        sizes = [layers[0].w.numel(), H, layers[1].w.numel(), AK]
+        self.flat_grad = torch.zeros(sum(sizes), **f32)
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        self.g_w1 = self.flat_grad[offs[0]:offs[1]].view_as(layers[0].w)
+        self.g_b1 = self.flat_grad[offs[1]:offs[2]]
+        self.g_w2 = self.flat_grad[offs[2]:offs[3]].view_as(layers[1].w)
+        self.g_b2 = self.flat_grad[offs[3]:offs[4]]
+        # Adam moments for the 12 parameter tensors
+        self.state = {}
+        for li, l in enumerate(layers):
+            for name in ("w", "w_mu", "w_sigma", "b", "b_mu", "b_sigma"):
+                t = getattr(l, name)
+                self.state[(li, name)] = (torch.zeros_like(t), torch.zeros_like(t))
+        self.step = torch.zeros((), **f32)
+        # static batch buffers
+        self.x = torch.empty(2 * B, self.L, dtype=self.cd, device=dev)
+        self.act = torch.empty(B, dtype=torch.int32, device=dev)
+        self.rew = torch.empty(B, **f32)
+        self.term = torch.empty(B, **f32)
+        self.td = torch.empty(B, **f32)
+        self.w_is = torch.empty(B, **f32)
+        self.dlogits = torch.empty(B, AK, dtype=self.cd, device=dev)
+        self.support = agent.atoms[0].contiguous()
+        self.refresh_effective()
+        self.refresh_target()
+
+    # ---- effective weights ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def refresh_effective(self):
+        for (w_e, b_e), l in zip(self.eff, self.layers):
+            w, b = l.effective()
+            w_e.copy_(w)
+            b_e.copy_(b)
+
+    @torch.no_grad()
+    def refresh_target(self):
+        for (w_t, b_t), l in zip(self.trg, self.agent.target.layers):
+            w, b = l.effective()
+            w_t.copy_(w)
+            b_t.copy_(b)
+
+    # ---- the two halves of an update ----------------------------------------------------------------------
+    def part1(self, indices, prios):
+        """Forward, loss, backward into flat_grad. indices int64 [B], prios float64 [B] (device)."""
+        a, L = self.agent, K.lib()
+        buf, B = a.experience, self.B
+        s = K.current_stream()
+        K.check(L.hb_replay_gather(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
+                                   K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), K.dptr(indices), B, self.L,
+                                   K.dptr(self.x), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew), K.dptr(self.term), s))
+        (w1, b1), (w2, b2) = self.eff
+        h = torch.relu_(torch.addmm(b1, self.x, w1))                # [2B, H]
+        logits_on = torch.addmm(b2, h, w2)                          # [2B, A*K]
+        (tw1, tb1), (tw2, tb2) = self.trg
+        logits_t = torch.addmm(tb2, torch.relu_(torch.addmm(tb1, self.x[B:], tw1)), tw2)
+        K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
+                                   K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), float(a.params.discount),
+                                   1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk,
+                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
+        hb, xb, dl = h[:B], self.x[:B], self.dlogits
+        self.g_w2.copy_(torch.mm(hb.t(), dl))
+        self.g_b2.copy_(dl.sum(0, dtype=torch.float32))
+        dh = torch.ops.aten.threshold_backward(torch.mm(dl, w2.t()), hb, 0.0)
+        self.g_w1.copy_(torch.mm(xb.t(), dh))
+        self.g_b1.copy_(dh.sum(0, dtype=torch.float32))
+        return self.td, self.w_is
+
+    def part2(self):
+        a, L = self.agent, K.lib()
+        p = a.params
+        s = K.current_stream()
+        grads = ((self.g_w1, self.g_b1), (self.g_w2, self.g_b2))
+        for li, l in enumerate(self.layers):
+            for names, noise, g, eff in ((("w", "w_mu", "w_sigma"), l.eps_w, grads[li][0], self.eff[li][0]),
+                                         (("b", "b_mu", "b_sigma"), l.eps_b, grads[li][1], self.eff[li][1])):
+                ps = [getattr(l, n) for n in names]
+                st = [self.state[(li, n)] for n in names]
+                K.check(L.hb_noisy_adam(K.dptr(ps[0]), K.dptr(ps[1]), K.dptr(ps[2]), K.dptr(noise), K.dptr(g),
+                                        K.dptr(st[0][0]), K.dptr(st[0][1]), K.dptr(st[1][0]), K.dptr(st[1][1]),
+                                        K.dptr(st[2][0]), K.dptr(st[2][1]), K.dptr(self.step), K.dptr(eff), _DT[self.cd],
+                                        ps[0].numel(), float(p.learning_rate), 0.9, 0.999, 3.125e-5, s))
+        self.step.add_(1.0)
+
+    def loss(self):
+        return torch.mean(self.td * self.w_is)

@@ -114,7 +114,7 @@ class DQNLearning:
 
 class DQNAgent:
     def __init__(self, observation_spec, action_spec, params: RlaxRainbowParams = RlaxRainbowParams(), device=None,
-                 process_group=None, use_graphs=True):
+                 process_group=None, use_graphs=True, use_fused_learner=True):
         if not callable(params.epsilon):
             eps = params.epsilon
             params = params._replace(epsilon=lambda ts: eps)
@@ -174,6 +174,8 @@ class DQNAgent:
         self._fused = self.device.type == "cuda" and self.distributional
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
         self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
+        self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
+        self.use_fused_learner = use_fused_learner
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
 
@@ -199,6 +201,8 @@ class DQNAgent:
     def _effective_weights(self):
         """[(W [in,out], bias [out])] of the online net in the GEMM dtype; recomputed only after the weights
         or the noise changed (the reference's noise is frozen, App. C-2, so acting re-uses them all the time)."""
+        if self._fl is not None:
+            return self._fl.eff  # kept current by hb_noisy_adam after every update
         if self._eff_cache is None:
             cd = _DTYPES[self.params.compute_dtype]
             self._eff_cache = [tuple(t.to(cd).contiguous() for t in layer.effective()) for layer in self.online.layers]
@@ -323,6 +327,8 @@ class DQNAgent:
         self._refresh_target_cache()
 
     def _refresh_target_cache(self):
+        if self._fl is not None:
+            self._fl.refresh_target()
         if self._trg_cache is None:
             return
         with torch.no_grad():  # IN PLACE: captured graphs hold these tensors
@@ -378,7 +384,32 @@ class DQNAgent:
         w_is = L.is_weights(prios, self._beta)
         return torch.mean(td * w_is), torch.abs(td).detach()
 
+    def _fused_learner(self):
+        """hanabi_agents.rlax_dqn.fused_learner.FusedLearner when applicable (GPU, C51 head, one hidden layer)."""
+        if self._fl is None and self._fused and self.use_fused_learner and len(self.online.layers) == 2:
+            from .fused_learner import FusedLearner
+
+            self._fl = FusedLearner(self)
+        return self._fl
+
+    def _sample_indices(self):
+        b = self.params.train_batch_size
+        if self.params.use_priority:
+            u = torch.rand(b, dtype=torch.float64, device=self.device) / b
+            return self.experience.sum_tree.per_sample_dev(u)
+        return self.experience.sample_indices_dev(b), torch.ones(b, dtype=torch.float64, device=self.device)
+
     def _update_part1(self):
+        fl = self._fused_learner()
+        if fl is not None:
+            if self.params.resample_noise:
+                self.online.resample()
+                self.target.resample()
+                fl.refresh_effective()
+                fl.refresh_target()
+            indices, prios = self._sample_indices()
+            td, _ = fl.part1(indices, prios)
+            return fl.loss(), indices, td
         indices, prios, tr = self._sample()
         if self.params.resample_noise:
             self.online.resample()
@@ -396,7 +427,10 @@ class DQNAgent:
         return loss.detach(), indices, new_prios
 
     def _update_part2(self, indices, new_prios):
-        self.optimizer.step()
+        if self._fl is not None:
+            self._fl.part2()
+        else:
+            self.optimizer.step()
         if self.params.use_priority:
             self.experience.update_priorities_dev(indices, new_prios)
 
@@ -443,8 +477,9 @@ class DQNAgent:
         world = dist.get_world_size(self.process_group)
         if world == 1:
             return
-        dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
-        self._flat_grad /= world
+        flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        flat /= world
 
     # ---- misc --------------------------------------------------------------------------------------------
     def __repr__(self):
@@ -460,4 +495,6 @@ class DQNAgent:
         self._eff_cache = None
         self.online.load_state_dict(torch.load(online_weights_file, map_location=self.device, weights_only=True))
         self.target.load_state_dict(torch.load(trg_weights_file, map_location=self.device, weights_only=True))
+        if self._fl is not None:
+            self._fl.refresh_effective()
         self._refresh_target_cache()

@@ -227,6 +227,37 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
                      uint8_t* ring_term_dev, int64_t n, int32_t obs_len, int32_t n_actions, int64_t capacity,
                      int64_t start, void* stream);
 
+/* ---- fused learner pieces (hanabi_agents/rlax_dqn/rlax_rainbow.py:152-217) ---------------
+ * dtype codes: 0 = f32, 1 = bf16, 2 = f16.
+ *
+ * hb_replay_gather: batch gather experience_buffer.py:83-87 straight into the GEMM operand:
+ *   x_dev [2*batch, obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
+ *   act_dev [B] int32, rew_dev [B] f32, term_dev [B] f32 (0/1).                                */
+int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
+                     const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
+                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t* act_dev, float* rew_dev, float* term_dev,
+                     void* stream);
+
+/* hb_c51_loss_grad: rlax_rainbow.py:172-200 on precomputed logits.
+ *   logits_online_dev [2B, A*K]: rows 0..B-1 = online(obs_tm1), rows B..2B-1 = online(obs_t);
+ *   logits_target_dev [B, A*K] = target(obs_t); support_dev [K] uniform atoms.
+ *   Outputs: td_dev [B] (cross-entropy "TD", its |.| is the new priority), w_dev [B] (IS
+ *   weights (1/P)^beta / max), dlogits_dev [B, A*K] = d mean(td * w) / d online(obs_tm1).
+ *   mask_terminal != 0 multiplies the discount by (1 - term) (off = the reference, App. C-5).   */
+int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
+                     const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
+                     float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
+                     int32_t n_atoms, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
+
+/* hb_noisy_adam: one Adam step (optix.adam form, rlax_rainbow.py:257) on the three parameters
+ * behind one merged NoisyLinear tensor W = w + w_mu + w_sigma * noise (noisy_mlp.py:61-91), given
+ * grad_dev = dLoss/dW (f32); writes the new merged tensor to eff_dev in eff_dtype. step_dev holds
+ * the number of steps already taken (the caller increments it once per update).                */
+int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float* noise_dev, const float* grad_dev,
+                  float* m_w_dev, float* v_w_dev, float* m_mu_dev, float* v_mu_dev, float* m_sigma_dev, float* v_sigma_dev,
+                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, float lr, float beta1, float beta2,
+                  float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

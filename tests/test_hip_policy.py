@@ -178,3 +178,52 @@ def test_batched_gpu_loss_equals_reference_loss_and_gradient():
         assert torch.allclose(td_a, td_b, rtol=1e-4, atol=1e-5)
         for ga, gb in zip(grads_a, grads_b):
             assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-7 + 2e-4 * float(gb.abs().max()))  # fp32 GEMMs of different M: summation order
+
+
+@pytest.mark.parametrize("mask,priority", [(False, False), (True, False), (True, True)])
+def test_fused_learner_equals_autograd_learner(mask, priority):
+    """FusedLearner (hb_replay_gather + hb_c51_loss_grad + hand-written backward + hb_noisy_adam) against the
+    PyTorch-autograd fp32 reference path (DQNLearning.loss + torch.optim.Adam) on the same batches."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    n, obs_len, n_act = 256, 658, 20
+    params = RlaxRainbowParams(use_priority=priority, train_batch_size=256, experience_buffer_size=256, target_update_period=3,
+                               mask_terminal=mask)
+    agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False,
+                       use_fused_learner=f) for f in (True, False)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    o2 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
+    act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+    rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
+    st = torch.randint(1, 3, (n,), device="cuda", generator=g).to(torch.int8)
+    for a in agents:
+        with torch.no_grad():
+            for layer in a.online.layers:     # exercise the bias-noise path too
+                layer.b_sigma.fill_(0.05)
+        a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+        a.add_experience((None, (o2, legal)), act, rew, st)
+        a.target.load_state_dict(a.online.state_dict())
+    idx = torch.randperm(n, device="cuda", generator=g)
+    pri = (torch.rand(n, device="cuda", generator=g, dtype=torch.float64) + 0.05) / n
+    fused, ref = agents
+    fused._sample_indices = lambda: (idx, pri)
+    ref._sample = lambda: (idx, pri, ref.experience.gather_dev(idx))
+    for step in range(5):
+        fused.update()
+        ref.update()
+        assert torch.allclose(fused.last_loss, ref.last_loss, rtol=2e-4), step
+    for (na, pa), (nb, pb) in zip(fused.online.named_parameters(), ref.online.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=2e-5), na
+    for pa, pb in zip(fused.target.parameters(), ref.target.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=2e-5)
+    if priority:
+        la = fused.experience.sum_tree.get_values(range(n))
+        lb = ref.experience.sum_tree.get_values(range(n))
+        assert np.allclose(la, lb, rtol=2e-3)
+    # the actor sees the freshly written effective weights
+    w_eff, _ = fused.online.layers[0].effective()
+    assert torch.allclose(fused._effective_weights()[0][0].float(), w_eff, rtol=1e-2, atol=1e-3)
