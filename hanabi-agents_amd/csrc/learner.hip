@@ -147,6 +147,21 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
 }
 
 // ---------------------------------------------------------------------------------------------
+// column sums out[j] = sum_i x[i, j] (bias gradients): 64 columns x 4 row groups per workgroup, fixed
+// summation order (deterministic), fp32 accumulation
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols)
+    for (int i = rg; i < rows; i += 4) s += ld<T>(x, static_cast<long long>(i) * cols + c);
+  part[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
 struct AdamArgs {
   float *w, *w_mu, *w_sigma;
   const float* noise;  // eps of the layer (same shape); bias noise for bias tensors
@@ -243,6 +258,20 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
   else if (dtype == 2) HB_C51(__half);
   else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
 #undef HB_C51
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_colsum(const void* x_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev, void* stream) {
+  if (!x_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (rows <= 0 || cols <= 0) return HB_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>((cols + 63) / 64)), block(256);
+  const int r = static_cast<int>(rows), c = static_cast<int>(cols);
+  if (dtype == 0) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, static_cast<const float*>(x_dev), r, c, out_dev);
+  else if (dtype == 1) hipLaunchKernelGGL((colsum_kernel<__hip_bfloat16>), grid, block, 0, s, static_cast<const __hip_bfloat16*>(x_dev), r, c, out_dev);
+  else if (dtype == 2) hipLaunchKernelGGL((colsum_kernel<__half>), grid, block, 0, s, static_cast<const __half*>(x_dev), r, c, out_dev);
+  else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

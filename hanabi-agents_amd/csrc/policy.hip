@@ -101,19 +101,17 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
   }
   qbuf[lane] = q;
   hb::wave_sync();
+  // per-game arg-max and candidate sets without touching memory again: every lane scans its game's A values
+  // in LDS, wave ballots give the legal / tie bit sets, the game's first lane shifts its A bits out
+  float best = -INFINITY;
+  if (on)
+    for (int i = 0; i < A; ++i) best = fmaxf(best, qbuf[gw * A + i]);
+  const unsigned long long legal_wave = __ballot(on && is_legal);
+  const unsigned long long ties_wave = __ballot(on && is_legal && q == best);
   if (on && a == 0) {
-    const float* qs = qbuf + gw * A;
-    float best = -INFINITY;
-    unsigned long long legal_mask = 0;
-    for (int i = 0; i < A; ++i) {
-      const float v = qs[i];
-      // -inf marks illegal moves; a legal move has a finite q
-      if (v > -INFINITY || legal[(g0 + gw) * A + i] != 0) legal_mask |= 1ull << i;
-      best = fmaxf(best, v);
-    }
-    unsigned long long ties = 0;
-    for (int i = 0; i < A; ++i)
-      if (((legal_mask >> i) & 1ull) && qs[i] == best) ties |= 1ull << i;
+    const unsigned long long mask_a = (1ull << A) - 1ull;
+    const unsigned long long legal_mask = (legal_wave >> (gw * A)) & mask_a;
+    const unsigned long long ties = (ties_wave >> (gw * A)) & mask_a;
     const unsigned long long gid = static_cast<unsigned long long>(first_gid + g0 + gw);
     uint32_t r[4];
     hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),

@@ -99,20 +99,20 @@ class FusedLearner:
                                    K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), K.dptr(indices), B, self.L,
                                    K.dptr(self.x), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew), K.dptr(self.term), s))
         (w1, b1), (w2, b2) = self.eff
-        h = torch.relu_(torch.addmm(b1, self.x, w1))                # [2B, H]
+        h = torch._addmm_activation(b1, self.x, w1, use_gelu=False)  # bias + ReLU in the GEMM epilogue, [2B, H]
         logits_on = torch.addmm(b2, h, w2)                          # [2B, A*K]
         (tw1, tb1), (tw2, tb2) = self.trg
-        logits_t = torch.addmm(tb2, torch.relu_(torch.addmm(tb1, self.x[B:], tw1)), tw2)
+        logits_t = torch.addmm(tb2, torch._addmm_activation(tb1, self.x[B:], tw1, use_gelu=False), tw2)
         K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), float(a.params.discount),
                                    1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk,
                                    K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
         hb, xb, dl = h[:B], self.x[:B], self.dlogits
         self.g_w2.copy_(torch.mm(hb.t(), dl))
-        self.g_b2.copy_(dl.sum(0, dtype=torch.float32))
+        K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, dl.shape[1], K.dptr(self.g_b2), s))
         dh = torch.ops.aten.threshold_backward(torch.mm(dl, w2.t()), hb, 0.0)
         self.g_w1.copy_(torch.mm(xb.t(), dh))
-        self.g_b1.copy_(dh.sum(0, dtype=torch.float32))
+        K.check(L.hb_colsum(K.dptr(dh), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         return self.td, self.w_is
 
     def part2(self):

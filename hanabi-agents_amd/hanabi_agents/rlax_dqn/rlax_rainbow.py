@@ -219,10 +219,8 @@ class DQNAgent:
         eff = self._effective_weights()
         cd = eff[0][0].dtype
         x = ops.obs_cast(obs.contiguous(), cd) if (obs.dtype == torch.int8 and cd != torch.float32) else obs.to(cd)
-        for i, (w, b) in enumerate(eff):
-            x = torch.addmm(b, x, w)
-            if i < len(eff) - 1:
-                x = torch.relu_(x)
+        for i, (w, b) in enumerate(eff):  # bias (+ ReLU) ride in the GEMM epilogue
+            x = torch._addmm_activation(b, x, w, use_gelu=False) if i < len(eff) - 1 else torch.addmm(b, x, w)
         self._draws += 1
         return ops.policy_act(x, legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
                               self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)

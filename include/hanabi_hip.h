@@ -249,6 +249,10 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
                      float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
 
+/* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:
+ * the column sums of dLoss/dlogits and of dLoss/dhidden). x_dev [rows, cols] contiguous.        */
+int hb_colsum(const void* x_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev, void* stream);
+
 /* hb_noisy_adam: one Adam step (optix.adam form, rlax_rainbow.py:257) on the three parameters
  * behind one merged NoisyLinear tensor W = w + w_mu + w_sigma * noise (noisy_mlp.py:61-91), given
  * grad_dev = dLoss/dW (f32); writes the new merged tensor to eff_dev in eff_dtype. step_dev holds
