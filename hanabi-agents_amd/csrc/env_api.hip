@@ -60,10 +60,17 @@ struct hb_env {
   long long first_gid;
   uint32_t* state;
   unsigned long long* illegal;
+  uint8_t* next_deck;  // [n, 64] deck pool: the deck each game is dealt at its next (re)deal
+  uint8_t* refill;     // [n] flags: pool entry consumed / stale
   const uint8_t* decks;
   int gpw;
   int device;
   hipEvent_t ev_start, ev_stop;
+  // the deck-pool refill runs on a private stream so it overlaps whatever the caller enqueues after a step
+  hipStream_t side;
+  hipEvent_t ev_step_done, ev_refill_done;
+  bool refill_in_flight;
+  bool async_refill;
 };
 
 using hb::fail;
@@ -118,12 +125,23 @@ int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t 
   e->decks = nullptr;
   e->gpw = 16;
   e->ev_start = e->ev_stop = nullptr;
+  e->side = nullptr;
+  e->ev_step_done = e->ev_refill_done = nullptr;
+  e->refill_in_flight = false;
+  e->async_refill = false;
   HB_HIP_OR(hipGetDevice(&e->device), delete e);
   const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->illegal), 8), { (void)hipFree(e->state); delete e; });
   HB_HIP_OR(hipMemset(e->state, 0, bytes), { hb_env_destroy(e); });
   HB_HIP_OR(hipMemset(e->illegal, 0, 8), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->next_deck), static_cast<size_t>(n_games) * hb::NEXT_DECK_BYTES), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->refill), static_cast<size_t>(n_games)), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMemset(e->next_deck, 0, static_cast<size_t>(n_games) * hb::NEXT_DECK_BYTES), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMemset(e->refill, 1, static_cast<size_t>(n_games)), { hb_env_destroy(e); });  // nothing generated yet
+  HB_HIP_OR(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking), { hb_env_destroy(e); });
+  HB_HIP_OR(hipEventCreateWithFlags(&e->ev_step_done, hipEventDisableTiming), { hb_env_destroy(e); });
+  HB_HIP_OR(hipEventCreateWithFlags(&e->ev_refill_done, hipEventDisableTiming), { hb_env_destroy(e); });
   *out = e;
   return HB_OK;
 }
@@ -132,6 +150,11 @@ int hb_env_destroy(hb_env* e) {
   if (!e) return HB_OK;
   if (e->state) (void)hipFree(e->state);
   if (e->illegal) (void)hipFree(e->illegal);
+  if (e->next_deck) (void)hipFree(e->next_deck);
+  if (e->refill) (void)hipFree(e->refill);
+  if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+  if (e->ev_step_done) (void)hipEventDestroy(e->ev_step_done);
+  if (e->ev_refill_done) (void)hipEventDestroy(e->ev_refill_done);
   delete e;
   return HB_OK;
 }
@@ -141,6 +164,9 @@ int64_t hb_env_num_games(const hb_env* e) { return e ? e->n : 0; }
 int hb_env_set_decks(hb_env* e, const uint8_t* decks_dev) {
   if (!e) return fail(HB_ERR_INVALID, "null env");
   e->decks = decks_dev;
+  e->refill_in_flight = false;
+  HB_HIP(hipDeviceSynchronize());
+  HB_HIP(hipMemset(e->refill, 1, static_cast<size_t>(e->n)));  // every pooled deck is stale now
   return HB_OK;
 }
 
@@ -159,9 +185,52 @@ int hb_env_set_profile_events(hb_env* e, void* start_event, void* stop_event) {
   return HB_OK;
 }
 
+static void fill_common(hb_env* e, hb::EnvArgs& a) {
+  a.state = e->state;
+  a.decks = e->decks;
+  a.next_deck = e->next_deck;
+  a.refill = e->refill;
+  a.n = e->n;
+  a.seed = e->seed;
+  a.first_gid = e->first_gid;
+  a.flags = e->cfg.flags;
+}
+
+// the caller's stream must not touch the pool while an asynchronous refill is still running
+static int join_refill(hb_env* e, void* stream) {
+  if (e->refill_in_flight) {
+    HB_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), e->ev_refill_done, 0));
+    e->refill_in_flight = false;
+  }
+  return HB_OK;
+}
+
+// regenerate consumed / stale deck-pool entries (cheap when nothing is flagged), in order on `stream`
+static int refill(hb_env* e, void* stream) {
+  hb::EnvArgs a{};
+  fill_common(e, a);
+  e->var->refill(a, static_cast<hipStream_t>(stream));
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+// same, but forked onto the env's private stream behind everything enqueued on `stream` so far; the next call
+// that needs the pool joins it (join_refill)
+static int refill_async(hb_env* e, void* stream) {
+  if (!e->async_refill) return refill(e, stream);
+  HB_HIP(hipEventRecord(e->ev_step_done, static_cast<hipStream_t>(stream)));
+  HB_HIP(hipStreamWaitEvent(e->side, e->ev_step_done, 0));
+  if (int rc = refill(e, e->side)) return rc;
+  HB_HIP(hipEventRecord(e->ev_refill_done, e->side));
+  e->refill_in_flight = true;
+  return HB_OK;
+}
+
 static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.state = e->state;
   a.decks = e->decks;
+  a.next_deck = e->next_deck;
+  a.refill = e->refill;
   a.illegal = e->illegal;
   a.n = e->n;
   a.seed = e->seed;
@@ -189,7 +258,10 @@ int hb_env_reset(hb_env* e, const uint8_t* mask_dev, int32_t start_player, void*
   a.mode = hb::MODE_RESET;
   a.mask = mask_dev;
   a.start_player = start_player;
-  return launch(e, a, stream);
+  if (int rc = join_refill(e, stream)) return rc;
+  if (int rc = refill(e, stream)) return rc;  // the pool must hold deck(game, current deal counter)
+  if (int rc = launch(e, a, stream)) return rc;
+  return refill(e, stream);
 }
 
 int hb_env_observe(hb_env* e, int8_t* obs_dev, int8_t* legal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev,
@@ -221,7 +293,9 @@ int hb_env_step(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* 
   a.agent_reward = agent_reward_dev;
   a.agent_step_type = agent_step_type_dev;
   a.score = score_dev;
-  return launch(e, a, stream);
+  if (int rc = join_refill(e, stream)) return rc;
+  if (int rc = launch(e, a, stream)) return rc;
+  return refill_async(e, stream);  // re-shuffle the pool entries this step consumed, off the caller's stream
 }
 
 #ifdef HB_STAMPS
@@ -234,7 +308,9 @@ int hb_env_step_stamped(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, 
   a.obs = obs_dev;
   a.legal = legal_dev;
   a.stamps = stamps_dev;
-  return launch(e, a, stream);
+  if (int rc = join_refill(e, stream)) return rc;
+  if (int rc = launch(e, a, stream)) return rc;
+  return refill_async(e, stream);
 }
 #endif
 
@@ -243,6 +319,14 @@ int hb_env_illegal_count(hb_env* e, int64_t* out) {
   unsigned long long v = 0;
   HB_HIP(hipMemcpy(&v, e->illegal, 8, hipMemcpyDeviceToHost));
   *out = static_cast<int64_t>(v);
+  return HB_OK;
+}
+
+int hb_env_set_async_refill(hb_env* e, int32_t on) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  HB_HIP(hipDeviceSynchronize());
+  e->refill_in_flight = false;
+  e->async_refill = on != 0;
   return HB_OK;
 }
 
@@ -256,7 +340,10 @@ int hb_env_import_state(hb_env* e, const uint32_t* rows_dev, void* stream) {
   if (!e || !rows_dev) return fail(HB_ERR_INVALID, "null argument");
   HB_HIP(hipMemcpyAsync(e->state, rows_dev, static_cast<size_t>(e->n) * e->var->state_words * 4, hipMemcpyDeviceToDevice,
                         static_cast<hipStream_t>(stream)));
-  return HB_OK;
+  // deal counters may have changed: every pooled deck is stale
+  if (int rc = join_refill(e, stream)) return rc;
+  HB_HIP(hipMemsetAsync(e->refill, 1, static_cast<size_t>(e->n), static_cast<hipStream_t>(stream)));
+  return refill(e, stream);
 }
 
 // ---- uniform-random legal policy (bench / tests) ------------------------------------------

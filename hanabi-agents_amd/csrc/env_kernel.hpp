@@ -31,6 +31,7 @@
 namespace hb {
 
 enum { MODE_STEP = 0, MODE_OBSERVE = 1, MODE_RESET = 2 };
+constexpr int NEXT_DECK_BYTES = 64;  // one pre-shuffled deck per game, padded to a 64-byte row
 enum { MV_PLAY = 0, MV_DISCARD = 1, MV_RCOLOR = 2, MV_RRANK = 3 };
 
 struct EnvArgs {
@@ -38,6 +39,8 @@ struct EnvArgs {
   const int32_t* actions;
   const uint8_t* mask;
   const uint8_t* decks;
+  uint8_t* next_deck;  // [n, 64]: the deck game g will be dealt at its next (re)deal, produced by refill_kernel
+  uint8_t* refill;     // [n]: 1 = next_deck[g] was consumed (or is stale) and must be regenerated
   int8_t* obs;
   int8_t* legal;
   float* reward;
@@ -186,16 +189,28 @@ __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride
   constexpr int CPR = L / 16, TAIL = L % 16;
   if constexpr (CPR > 0) {
     const int chunks = nvalid * CPR;
-#pragma unroll 2
-    for (int c = lane; c < chunks; c += 64) {
-      const int g = c / CPR, l = c - g * CPR;
-      const uint32_t v = reinterpret_cast<const uint16_t*>(bits + g * row_stride)[l];
-      u32x4 o;
-      o.x = spread4(v);
-      o.y = spread4(v >> 4);
-      o.z = spread4(v >> 8);
-      o.w = spread4(v >> 12);
-      *reinterpret_cast<u32x4_unaligned*>(out + g * L + 16 * l) = o;
+    // four chunks per lane per trip: the four LDS reads are issued back to back, then four stores
+    for (int c0 = lane; c0 < chunks; c0 += 256) {
+      uint32_t v[4];
+      int off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 64 * u;
+        const int g = c / CPR, l = c - g * CPR;
+        off[u] = g * L + 16 * l;
+        v[u] = c < chunks ? reinterpret_cast<const uint16_t*>(bits + g * row_stride)[l] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (c0 + 64 * u < chunks) {
+          u32x4 o;
+          o.x = spread4(v[u]);
+          o.y = spread4(v[u] >> 4);
+          o.z = spread4(v[u] >> 8);
+          o.w = spread4(v[u] >> 12);
+          *reinterpret_cast<u32x4_unaligned*>(out + off[u]) = o;
+        }
+      }
     }
   }
   if constexpr (TAIL > 0) {
@@ -240,9 +255,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   const long long gi = g0 + lane;
   int uid_in = 0;
   bool mask_in = true;
+  uint4 nd[4];  // this game's pre-shuffled next deck (64 B), in flight while the rules run; used only on a re-deal
   if (active) {
     if (mode == MODE_STEP) uid_in = a.actions[gi];
     if (mode == MODE_RESET && a.mask) mask_in = a.mask[gi] != 0;
+    if (mode != MODE_OBSERVE) {
+      const uint4* ndp = reinterpret_cast<const uint4*>(a.next_deck + gi * NEXT_DECK_BYTES);
+      nd[0] = ndp[0]; nd[1] = ndp[1]; nd[2] = ndp[2]; nd[3] = ndp[3];
+    }
   }
 
   // ---- phase 1: state rows HBM -> LDS (coalesced 16-byte loads) ---------------------------
@@ -419,37 +439,13 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   }
 
   HB_STAMP(3);
-  // ---- phase 2b: wave-cooperative re-deal of finished / masked games -----------------------
-  {
-    unsigned long long todo = __ballot(need_reset);
-    while (todo) {
-      const int src = __ffsll(static_cast<long long>(todo)) - 1;
-      todo &= todo - 1;
-      uint8_t* deckb = reinterpret_cast<uint8_t*>(srow + src * K::SWP + K::W_DECK);
-      const unsigned long long gid = static_cast<unsigned long long>(a.first_gid + g0 + src);
-      if (a.decks) {
-        if (lane < K::D) deckb[lane] = a.decks[(g0 + src) * K::D + lane];
-      } else {
-        const uint32_t episode = __shfl(w6, src);
-        uint32_t out[4];
-        philox4x32_10(static_cast<uint32_t>(lane), episode, static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
-                      static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), out);
-        // sort key: 26 random bits, the deck position in the low 6 bits -> all keys distinct
-        const uint32_t key = (out[0] & ~63u) | static_cast<uint32_t>(lane);
-        // rank among the D keys: D scalar broadcasts (v_readlane with a constant lane) + compare + add-carry
-        int rank = 0;
-        static_for<K::D>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          const uint32_t ki = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), i));
-          rank += ki < key ? 1 : 0;
-        });
-        if (lane < K::D) {
-          const int col = lane / K::CPC, k = lane - col * K::CPC;
-          const int rk = k < 3 ? 0 : 1 + (k - 3) / 2;
-          deckb[rank] = static_cast<uint8_t>(col * R + rk);
-        }
-      }
-    }
+  // ---- phase 2b: a finished / masked game takes its pre-shuffled next deck (lane-local copy into the LDS row);
+  // the shuffle itself happens off this kernel's critical path in refill_kernel -----------------------------
+  if (active && need_reset) {
+    const uint32_t* ndw = reinterpret_cast<const uint32_t*>(nd);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) row[K::W_DECK + i] = ndw[i];
+    a.refill[gi] = 1;
   }
   HB_STAMP(4);
   wave_sync();
@@ -637,6 +633,57 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   HB_STAMP_REAL(11);
 }
 
+// Deck pool refill: regenerates next_deck[g] for every game whose flag is set. One wavefront scans 64 games
+// and shuffles the flagged ones one at a time with all lanes: lane j draws Philox4x32-10(j, episode, game id;
+// seed), key = 26 random bits | j (all distinct); its rank among the D keys comes from D v_readlane
+// broadcasts + compare + add-carry; card j of the canonical deck lands at position rank. `episode` is the
+// game's deal counter (state word 6), so deck(g, e) is a pure function of (seed, global game id, e).
+template <class K>
+__global__ __launch_bounds__(256) void refill_kernel(const EnvArgs a) {
+  constexpr int GR = 16;  // games scanned per wavefront: few enough that a wave rarely shuffles more than one deck
+  const int lane = threadIdx.x & 63;
+  const long long g0 = (static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GR;
+  if (g0 >= a.n) return;
+  const long long gi = g0 + lane;
+  const bool mine = lane < GR && gi < a.n && a.refill[gi] != 0;
+  unsigned long long todo = __ballot(mine);
+  while (todo) {
+    const int src = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const long long g = g0 + src;
+    uint8_t* dst = a.next_deck + g * NEXT_DECK_BYTES;
+    if (a.decks) {
+      if (lane < K::D) dst[lane] = a.decks[g * K::D + lane];
+    } else {
+      const uint32_t episode = a.state[g * K::SW + 6];
+      const unsigned long long gid = static_cast<unsigned long long>(a.first_gid + g);
+      uint32_t out[4];
+      philox4x32_10(static_cast<uint32_t>(lane), episode, static_cast<uint32_t>(gid), static_cast<uint32_t>(gid >> 32),
+                    static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), out);
+      const uint32_t key = (out[0] & ~63u) | static_cast<uint32_t>(lane);
+      int rank = 0;
+      static_for<K::D>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t ki = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), i));
+        rank += ki < key ? 1 : 0;
+      });
+      if (lane < K::D) {
+        const int col = lane / K::CPC, k = lane - col * K::CPC;
+        const int rk = k < 3 ? 0 : 1 + (k - 3) / 2;
+        dst[rank] = static_cast<uint8_t>(col * K::R + rk);
+      }
+    }
+  }
+  if (mine) a.refill[gi] = 0;
+}
+
+template <class K>
+void launch_refill(const EnvArgs& a, hipStream_t stream) {
+  const unsigned blocks = static_cast<unsigned>((a.n + 63) / 64);  // 4 wavefronts x 16 games per workgroup
+  if (blocks == 0) return;
+  hipLaunchKernelGGL((refill_kernel<K>), dim3(blocks), dim3(256), 0, stream, a);
+}
+
 template <class K, int G>
 void launch_env(const EnvArgs& a, hipStream_t stream) {
   const long long per_block = 4LL * G;
@@ -652,13 +699,13 @@ using LaunchFn = void (*)(const EnvArgs&, hipStream_t);
 struct EnvVariant {
   int P, C, R, H, INFO, LIFE;
   int obs_len, n_actions, deck, state_words;
-  LaunchFn g16, g32, g64;
+  LaunchFn g16, g32, g64, refill;
 };
 
 template <class K>
 constexpr EnvVariant make_variant() {
   return EnvVariant{K::P, K::C, K::R, K::H, K::INFO, K::LIFE, K::OBS_LEN, K::A, K::D, K::SW,
-                    &launch_env<K, 16>, &launch_env<K, 32>, &launch_env<K, 64>};
+                    &launch_env<K, 16>, &launch_env<K, 32>, &launch_env<K, 64>, &launch_refill<K>};
 }
 
 }  // namespace hb

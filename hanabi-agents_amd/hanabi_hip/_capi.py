@@ -64,6 +64,7 @@ SIGNATURES = {
     "hb_env_import_state": (C.c_int, [_P, _P, _P]),
     "hb_random_legal_actions": (C.c_int, [_P, _I64, _I32, _U64, _U64, _I64, _P, _P]),
     "hb_env_set_games_per_wave": (C.c_int, [_P, _I32]),
+    "hb_env_set_async_refill": (C.c_int, [_P, _I32]),
     "hb_env_set_profile_events": (C.c_int, [_P, _P, _P]),
     "hb_tree_create": (C.c_int, [_I64, C.POINTER(_P)]),
     "hb_tree_destroy": (C.c_int, [_P]),

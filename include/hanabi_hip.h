@@ -144,6 +144,14 @@ int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_
 /* Tuning knob for measurements: games handled per 64-lane wavefront (16, 32 or 64).    */
 int hb_env_set_games_per_wave(hb_env* env, int32_t g);
 
+/* Deck-pool refill placement. Every game keeps its NEXT deck pre-shuffled in HBM, so a re-deal inside
+ * hb_env_step is a 52-byte copy; the shuffles that replace consumed decks run in a second small kernel.
+ * on == 0 (default): it runs in order on the caller's stream right after the step kernel (graph-capturable).
+ * on != 0: it is forked onto a stream owned by the env and joined by the next call that needs the pool, so
+ * it overlaps the caller's following work — worthwhile only when the caller is not launch-bound (the fork /
+ * join costs four extra runtime calls per step; measured slower in bench.py). Synchronises the device.    */
+int hb_env_set_async_refill(hb_env* env, int32_t on);
+
 /* Measurement hook: when both are non-NULL (hipEvent_t handles), every following env kernel
  * launch records its own start/stop into them (hipExtLaunchKernelGGL), i.e. the dispatch's
  * begin/end timestamps rather than a pair of stream markers. NULL, NULL turns it off.      */
