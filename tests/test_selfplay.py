@@ -62,3 +62,31 @@ def test_graft_smoke():
     import __graft_entry__ as g
 
     g.smoke()
+
+
+@pytest.mark.parametrize("game,players,kwargs", [
+    ("Hanabi-Full", 5, dict()),                                            # BASELINE config 4 shape: obs 1280, 48 moves
+    ("Hanabi-Full", 2, dict(distributional=False, use_priority=False)),    # BASELINE config 2: vanilla double-DQN, uniform replay
+    ("Hanabi-Small", 3, dict(compute_dtype="bfloat16")),
+])
+def test_other_configs_run_end_to_end(game, players, kwargs):
+    import torch
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    n = 512
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config(game, players, flags), n_games=n, seed=11)
+    params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=8192, mask_terminal=True, **kwargs)
+    agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
+              for s in range(players)]
+    sess = SelfPlaySession(env, agents, updates_per_step=1)
+    sess.run(6 * players)
+    assert env.illegal_count() == 0
+    assert sess.grad_steps > 0
+    for a in agents:
+        assert torch.isfinite(a.last_loss).item()
+        assert a.experience.size > 0
+    assert int(env.current_player()[0]) == (6 * players) % players and bool((env.current_player() == env.current_player()[0]).all())
