@@ -49,13 +49,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(const int8_t* __restrict__ ring_tm1, const int8_t* __restrict__ ring_t,
                                                      const int8_t* __restrict__ ring_act, const float* __restrict__ ring_rew,
                                                      const uint8_t* __restrict__ ring_term, const int64_t* __restrict__ idx,
-                                                     int B, int L, T* __restrict__ x, int32_t* __restrict__ act,
+                                                     int B, int L, T* __restrict__ x, int x_ld, int32_t* __restrict__ act,
                                                      float* __restrict__ rew, float* __restrict__ term) {
   const int r = blockIdx.x;  // output row 0..2B-1
   const int b = r < B ? r : r - B;
   const long long slot = idx[b];
   const int8_t* src = (r < B ? ring_tm1 : ring_t) + slot * L;
-  T* dst = x + static_cast<long long>(r) * L;
+  T* dst = x + static_cast<long long>(r) * x_ld;  // row stride x_ld >= L: padding columns are left untouched (zero)
   for (int j = threadIdx.x; j < L; j += 256) st<T>(dst, j, static_cast<float>(src[j]));
   if (r < B && threadIdx.x == 0) {
     act[b] = ring_act[slot];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
                                                   const int32_t* __restrict__ act, const float* __restrict__ rew,
                                                   const float* __restrict__ term, const double* __restrict__ prios,
                                                   const float* __restrict__ beta_dev, float discount, int mask_terminal,
-                                                  const float* __restrict__ support, int B, int A, int K,
+                                                  const float* __restrict__ support, int B, int A, int K, int rs,
                                                   float* __restrict__ td_out, float* __restrict__ w_out,
                                                   T* __restrict__ dlogits) {
   extern __shared__ float lds[];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   wmax = wave_max(wmax);
   const float w_b = powf(static_cast<float>(1.0 / prios[b]), beta) / wmax;
   // ---- double-Q selector: q_sel[a] = mean(softmax(online(obs_t))[a] * z) (no legal mask, as the reference)
-  const T* row_sel = logits_on + static_cast<long long>(B + b) * AK;
+  const T* row_sel = logits_on + static_cast<long long>(B + b) * rs;  // rows are rs >= A*K elements apart
   for (int e = lane; e < AK; e += 64) sel[e] = ld<T>(row_sel, e);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   const int a_star = __ffsll(static_cast<long long>(hit)) - 1;  // lowest index among ties, like argmax
   // ---- target distribution p = softmax(target(obs_t)[a*]) and its projection onto the support
   const bool atom = lane < K;
-  const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * AK + a_star * K + lane) : -INFINITY;
+  const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * rs + a_star * K + lane) : -INFINITY;
   const float mt = wave_max(lt);
   const float et = atom ? __expf(lt - mt) : 0.f;
   const float p = et / wave_sum(et);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   if (!atom) target = 0.f;
   // ---- cross-entropy against log_softmax(online(obs_tm1)[a_tm1]) and its gradient
   const int a_tm1 = act[b];
-  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * AK + a_tm1 * K + lane) : -INFINITY;
+  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * rs + a_tm1 * K + lane) : -INFINITY;
   const float m1 = wave_max(l1);
   const float e1 = atom ? __expf(l1 - m1) : 0.f;
   const float s1 = wave_sum(e1);
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
     td_out[b] = td;
     w_out[b] = w_b;
   }
-  T* drow = dlogits + static_cast<long long>(b) * AK;
-  for (int e = lane; e < AK; e += 64) st<T>(drow, e, 0.f);
+  T* drow = dlogits + static_cast<long long>(b) * rs;
+  for (int e = lane; e < rs; e += 64) st<T>(drow, e, 0.f);  // padding columns included
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (atom) st<T>(drow, a_tm1 * K + lane, (w_b / static_cast<float>(B)) * (e1 / s1 * tsum - target));
@@ -170,6 +170,7 @@ struct AdamArgs {
   const float* step;   // number of completed Adam steps (device scalar)
   void* eff;           // merged tensor in the GEMM dtype for the next forward
   long long n;
+  int cols, eff_ld;    // parameter tensors are [n/cols, cols] row-major; eff rows are eff_ld >= cols elements apart
   float lr, b1, b2, eps;
 };
 
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
     m = a.m_sg[i]; v = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], g * nz, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
-    st<T>(eff, i, w + mu + sg * nz);
+    st<T>(eff, (i / a.cols) * a.eff_ld + (i % a.cols), w + mu + sg * nz);
   }
 }
 
@@ -215,21 +216,22 @@ extern "C" {
 
 int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
                      const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
-                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t* act_dev, float* rew_dev, float* term_dev,
-                     void* stream) {
+                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
+                     float* term_dev, void* stream) {
   if (!ring_obs_tm1_dev || !ring_obs_t_dev || !ring_act_dev || !ring_rew_dev || !ring_term_dev || !idx_dev || !x_dev ||
       !act_dev || !rew_dev || !term_dev)
     return fail(HB_ERR_INVALID, "null argument");
   if (batch <= 0) return HB_OK;
+  if (x_ld < obs_len) return fail(HB_ERR_INVALID, "x_ld must be >= obs_len");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(2 * batch)), block(256);
   const int B = static_cast<int>(batch);
   if (x_dtype == 0)
-    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
   else if (x_dtype == 1)
-    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
   else if (x_dtype == 2)
-    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
   else
     return fail(HB_ERR_INVALID, "x_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
@@ -239,12 +241,13 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
-                     int32_t n_atoms, float* td_dev, float* w_dev, void* dlogits_dev, void* stream) {
+                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream) {
   if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev ||
       !support_dev || !td_dev || !w_dev || !dlogits_dev)
     return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64 || n_atoms < 2 || n_atoms > 64) return fail(HB_ERR_INVALID, "need n_actions <= 64 and 2 <= n_atoms <= 64");
   if (batch <= 0) return HB_OK;
+  if (row_stride < n_actions * n_atoms) return fail(HB_ERR_INVALID, "row_stride must be >= n_actions * n_atoms");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>((batch + 3) / 4)), block(256);
   const size_t lds = 4 * (static_cast<size_t>(n_actions) * n_atoms + 64) * sizeof(float);
@@ -252,7 +255,7 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
 #define HB_C51(T)                                                                                                       \
   hipLaunchKernelGGL((c51_kernel<T>), grid, block, lds, s, static_cast<const T*>(logits_online_dev),                    \
                      static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, discount, \
-                     mask_terminal, support_dev, B, n_actions, n_atoms, td_dev, w_dev, static_cast<T*>(dlogits_dev))
+                     mask_terminal, support_dev, B, n_actions, n_atoms, row_stride, td_dev, w_dev, static_cast<T*>(dlogits_dev))
   if (dtype == 0) HB_C51(float);
   else if (dtype == 1) HB_C51(__hip_bfloat16);
   else if (dtype == 2) HB_C51(__half);
@@ -278,14 +281,15 @@ int hb_colsum(const void* x_dev, int32_t dtype, int64_t rows, int64_t cols, floa
 
 int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float* noise_dev, const float* grad_dev,
                   float* m_w_dev, float* v_w_dev, float* m_mu_dev, float* v_mu_dev, float* m_sigma_dev, float* v_sigma_dev,
-                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, float lr, float beta1, float beta2,
-                  float eps, void* stream) {
+                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, int32_t cols, int32_t eff_ld, float lr,
+                  float beta1, float beta2, float eps, void* stream) {
   if (!w_dev || !w_mu_dev || !w_sigma_dev || !noise_dev || !grad_dev || !m_w_dev || !v_w_dev || !m_mu_dev || !v_mu_dev ||
       !m_sigma_dev || !v_sigma_dev || !step_dev || !eff_dev)
     return fail(HB_ERR_INVALID, "null argument");
   if (n <= 0) return HB_OK;
+  if (cols < 1 || eff_ld < cols || n % cols) return fail(HB_ERR_INVALID, "need cols >= 1, eff_ld >= cols and n a multiple of cols");
   AdamArgs a{w_dev, w_mu_dev, w_sigma_dev, noise_dev, grad_dev, m_w_dev, v_w_dev, m_mu_dev, v_mu_dev, m_sigma_dev, v_sigma_dev,
-             step_dev, eff_dev, n, lr, beta1, beta2, eps};
+             step_dev, eff_dev, n, cols, eff_ld, lr, beta1, beta2, eps};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eff_dtype == 0) launch_adam<float>(a, s);
   else if (eff_dtype == 1) launch_adam<__hip_bfloat16>(a, s);

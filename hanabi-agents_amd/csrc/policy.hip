@@ -33,11 +33,14 @@ __device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { retu
 template <>
 __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte access: one dwordx4 instruction on gfx950
+
 constexpr int MAX_WAVE_ELEMS = 64 * 64;  // LDS floats per wavefront: covers A*K <= 4096 per game group
 
 template <typename T>
 __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logits, const int8_t* __restrict__ legal,
-                                                     const float* __restrict__ support, long long n, int A, int K,
+                                                     const float* __restrict__ support, long long n, int A, int K, int ld,
                                                      float epsilon, unsigned long long seed, unsigned long long draw,
                                                      long long first_gid, int32_t* __restrict__ actions,
                                                      float* __restrict__ q_out) {
@@ -52,10 +55,13 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
   const long long left = n - g0;
   const int ng = left < gpw ? static_cast<int>(left) : gpw;
   const int elems = ng * A * K;
-  const T* src = logits + g0 * A * K;
+  const T* src = logits + g0 * ld;
   // stage HBM -> LDS: 4 elements per lane per load, FOUR independent loads in flight per lane before the first
-  // LDS write (a wave owns ~12 KB of logits; issuing the loads back-to-back hides the HBM latency once, not 12x)
-  if (((A * K) & 3) == 0) {
+  // LDS write (a wave owns ~12 KB of logits; issuing the loads back-to-back hides the HBM latency once, not 12x).
+  // Rows are ld >= A*K elements apart (the GEMM output may be padded): element e of the wave's block lives at
+  // src[(e / AK) * ld + e % AK].
+  const int AK = A * K;
+  if ((AK & 3) == 0 && (ld & 3) == 0) {
     for (int base = 0; base < elems; base += 1024) {
       int e[4];
       float4 v[4];
@@ -63,10 +69,12 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
       for (int u = 0; u < 4; ++u) {
         e[u] = base + u * 256 + lane * 4;
         if (e[u] < elems) {
+          const int gq = e[u] / AK;
+          const T* p = src + static_cast<long long>(gq) * ld + (e[u] - gq * AK);
           if constexpr (sizeof(T) == 4) {
-            v[u] = *reinterpret_cast<const float4*>(src + e[u]);
+            v[u] = *reinterpret_cast<const float4*>(p);
           } else {
-            const uint2 raw = *reinterpret_cast<const uint2*>(src + e[u]);
+            const uint2 raw = *reinterpret_cast<const uint2*>(p);
             const T* t = reinterpret_cast<const T*>(&raw);
             v[u] = make_float4(to_f32<T>(t[0]), to_f32<T>(t[1]), to_f32<T>(t[2]), to_f32<T>(t[3]));
           }
@@ -77,7 +85,10 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
         if (e[u] < elems) { buf[e[u]] = v[u].x; buf[e[u] + 1] = v[u].y; buf[e[u] + 2] = v[u].z; buf[e[u] + 3] = v[u].w; }
     }
   } else {
-    for (int e = lane; e < elems; e += 64) buf[e] = to_f32<T>(src[e]);
+    for (int e = lane; e < elems; e += 64) {
+      const int gq = e / AK;
+      buf[e] = to_f32<T>(src[static_cast<long long>(gq) * ld + (e - gq * AK)]);
+    }
   }
   hb::wave_sync();
   const int gw = lane / A, a = lane - gw * A;
@@ -131,14 +142,14 @@ __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logit
 }
 
 template <typename T>
-int launch_policy(const void* logits, const int8_t* legal, const float* support, int64_t n, int A, int K, float eps,
+int launch_policy(const void* logits, const int8_t* legal, const float* support, int64_t n, int A, int K, int ld, float eps,
                   uint64_t seed, uint64_t draw, int64_t first_gid, int32_t* actions, float* q_out, hipStream_t s) {
   const int gpw = 64 / A;
   const long long per_block = 4LL * gpw;
   const unsigned blocks = static_cast<unsigned>((n + per_block - 1) / per_block);
   const size_t lds = 4 * (static_cast<size_t>(gpw) * A * K + 64) * sizeof(float);
   hipLaunchKernelGGL((policy_kernel<T>), dim3(blocks), dim3(256), lds, s, static_cast<const T*>(logits), legal, support,
-                     static_cast<long long>(n), A, K, eps, static_cast<unsigned long long>(seed),
+                     static_cast<long long>(n), A, K, ld, eps, static_cast<unsigned long long>(seed),
                      static_cast<unsigned long long>(draw), static_cast<long long>(first_gid), actions, q_out);
   HB_HIP(hipGetLastError());
   return HB_OK;
@@ -147,9 +158,6 @@ int launch_policy(const void* logits, const int8_t* legal, const float* support,
 // ---------------------------------------------------------------------------------------------
 // replay insert: the acting seat's N transitions -> ring slots (start + i) mod cap, one launch
 // ---------------------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_u __attribute__((aligned(1)));
-
 // copies `bytes` (16 bytes per lane, tail bytewise) to up to two destinations; rows are obs_len bytes apart, so
 // neither side is more than byte-aligned after a ring wrap: unaligned dwordx4 accesses (one instruction on gfx950)
 __device__ __forceinline__ void copy2(const int8_t* __restrict__ src, int8_t* __restrict__ d0, int8_t* __restrict__ d1,
@@ -218,42 +226,53 @@ __global__ __launch_bounds__(256) void replay_insert_obs_kernel(const InsertArgs
   }
 }
 
-// int8 0/1 observations -> bf16 / f16 GEMM operand: 16 bytes in, 32 bytes out per lane
+// int8 0/1 observations [rows, cols] -> bf16 / f16 GEMM operand with row stride out_ld >= cols (padding columns are
+// never written: the caller zeroes them once). Lane -> (row, 16-column chunk): one unaligned 16-byte load, two
+// 16-byte stores; the cols % 16 tail is done element-wise by the same lanes.
 template <typename T>
-__global__ __launch_bounds__(256) void obs_cast_kernel(const int8_t* __restrict__ in, T* __restrict__ out, long long n) {
+__global__ __launch_bounds__(256) void obs_cast_kernel(const int8_t* __restrict__ in, T* __restrict__ out, long long rows,
+                                                       int cols, int out_ld) {
+  const int cpr = cols >> 4, tail = cols & 15;
+  const long long chunks = rows * cpr;
   const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
-  const long long vec = n >> 4;
-  for (long long i = tid; i < vec; i += nthreads) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(in + (i << 4));
+  for (long long c = tid; c < chunks; c += nthreads) {
+    const long long r = c / cpr;
+    const int l = static_cast<int>(c - r * cpr);
+    const u32x4 raw = *reinterpret_cast<const u32x4_u*>(in + r * cols + 16 * l);
     const int8_t* b = reinterpret_cast<const int8_t*>(&raw);
     T o[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[j] = static_cast<T>(static_cast<float>(b[j]));
-    uint4* dst = reinterpret_cast<uint4*>(out + (i << 4));
-    dst[0] = *reinterpret_cast<const uint4*>(o);
-    dst[1] = *reinterpret_cast<const uint4*>(o + 8);
+    u32x4_u* dst = reinterpret_cast<u32x4_u*>(out + r * out_ld + 16 * l);
+    dst[0] = *reinterpret_cast<const u32x4*>(o);
+    dst[1] = *reinterpret_cast<const u32x4*>(o + 8);
   }
-  for (long long j = (vec << 4) + tid; j < n; j += nthreads) out[j] = static_cast<T>(static_cast<float>(in[j]));
+  if (tail)
+    for (long long e = tid; e < rows * tail; e += nthreads) {
+      const long long r = e / tail;
+      const int j = cpr * 16 + static_cast<int>(e - r * tail);
+      out[r * out_ld + j] = static_cast<T>(static_cast<float>(in[r * cols + j]));
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t n_elements, void* stream) {
+int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t rows, int32_t cols, int32_t out_ld,
+                void* stream) {
   if (!obs_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
-  if (n_elements <= 0) return HB_OK;
-  if ((reinterpret_cast<uintptr_t>(obs_dev) & 15) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
-    return fail(HB_ERR_ALIGN, "obs_dev / out_dev must be 16-byte aligned");
-  long long blocks = ((n_elements >> 4) + 255) / 256;
+  if (rows <= 0 || cols <= 0) return HB_OK;
+  if (out_ld < cols) return fail(HB_ERR_INVALID, "out_ld must be >= cols");
+  long long blocks = ((rows * (cols >> 4)) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_dtype == 1)
-    hipLaunchKernelGGL((obs_cast_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__hip_bfloat16*>(out_dev), static_cast<long long>(n_elements));
+    hipLaunchKernelGGL((obs_cast_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__hip_bfloat16*>(out_dev), static_cast<long long>(rows), cols, out_ld);
   else if (out_dtype == 2)
-    hipLaunchKernelGGL((obs_cast_kernel<__half>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__half*>(out_dev), static_cast<long long>(n_elements));
+    hipLaunchKernelGGL((obs_cast_kernel<__half>), dim3(blocks), dim3(256), 0, s, obs_dev, static_cast<__half*>(out_dev), static_cast<long long>(rows), cols, out_ld);
   else
     return fail(HB_ERR_INVALID, "out_dtype must be 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
@@ -261,20 +280,21 @@ int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t
 }
 
 int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* legal_dev, const float* support_dev,
-                  int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,
-                  int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream) {
+                  int64_t n_games, int32_t n_actions, int32_t n_atoms, int32_t row_stride, float epsilon, uint64_t seed,
+                  uint64_t draw, int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream) {
   if (!logits_dev || !legal_dev || !support_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
   if (n_atoms < 1 || (64 / n_actions) * n_actions * n_atoms > MAX_WAVE_ELEMS)
     return fail(HB_ERR_INVALID, "n_actions * n_atoms too large for the LDS staging buffer");
   if (n_games <= 0) return HB_OK;
+  if (row_stride < n_actions * n_atoms) return fail(HB_ERR_INVALID, "row_stride must be >= n_actions * n_atoms");
   const int esz = logits_dtype == 0 ? 4 : 2;
   if (reinterpret_cast<uintptr_t>(logits_dev) & (4 * esz - 1)) return fail(HB_ERR_ALIGN, "logits_dev must be 16-byte (fp32) / 8-byte (16-bit) aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (logits_dtype) {
-    case 0: return launch_policy<float>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
-    case 1: return launch_policy<__hip_bfloat16>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
-    case 2: return launch_policy<__half>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+    case 0: return launch_policy<float>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, row_stride, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+    case 1: return launch_policy<__hip_bfloat16>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, row_stride, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
+    case 2: return launch_policy<__half>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, row_stride, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);
   }
   return fail(HB_ERR_INVALID, "logits_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
 }

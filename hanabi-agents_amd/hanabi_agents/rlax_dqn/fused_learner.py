@@ -41,10 +41,15 @@ class FusedLearner:
         B, AK = self.B, self.A * self.Kk
         H = layers[0].out_features
         f32 = dict(dtype=torch.float32, device=dev)
-        # merged tensors per layer: (weight, bias); effective values in the GEMM dtype
-        self.eff = [(torch.empty(l.in_features, l.out_features, dtype=self.cd, device=dev),
-                     torch.empty(l.out_features, dtype=self.cd, device=dev)) for l in layers]
-        self.trg = [(torch.empty_like(w), torch.empty_like(b)) for w, b in self.eff]
+        # merged tensors per layer: (weight, bias); effective values in the GEMM dtype, PADDED to the shapes
+        # hipBLASLt runs fastest (scripts/gemm_probe.py: K 658 -> 704: 39 -> 27 us, N 1020 -> 1024: 61 -> 43 us at
+        # 32 768 rows). Padding rows / columns are zero and never written, so results are unchanged.
+        pad = (lambda v, m: (v + m - 1) // m * m) if self.cd != torch.float32 else (lambda v, m: v)
+        self.Kp = pad(self.L, 64)           # first-layer K
+        self.Np = pad(AK, 64)               # second-layer N (logits row stride)
+        self.eff = [(torch.zeros(self.Kp, H, dtype=self.cd, device=dev), torch.zeros(H, dtype=self.cd, device=dev)),
+                    (torch.zeros(H, self.Np, dtype=self.cd, device=dev), torch.zeros(self.Np, dtype=self.cd, device=dev))]
+        self.trg = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in self.eff]
         # flat gradient buffer [dW1 | db1 | dW2 | db2] (fp32), one all-reduce bucket
         sizes = [layers[0].w.numel(), H, layers[1].w.numel(), AK]
         self.flat_grad = torch.zeros(sum(sizes), **f32)
@@ -63,31 +68,34 @@ class FusedLearner:
                 self.state[(li, name)] = (torch.zeros_like(t), torch.zeros_like(t))
         self.step = torch.zeros((), **f32)
         # static batch buffers
-        self.x = torch.empty(2 * B, self.L, dtype=self.cd, device=dev)
+        self.x = torch.zeros(2 * B, self.Kp, dtype=self.cd, device=dev)   # pad columns stay zero
         self.act = torch.empty(B, dtype=torch.int32, device=dev)
         self.rew = torch.empty(B, **f32)
         self.term = torch.empty(B, **f32)
         self.td = torch.empty(B, **f32)
         self.w_is = torch.empty(B, **f32)
-        self.dlogits = torch.empty(B, AK, dtype=self.cd, device=dev)
+        self.dlogits = torch.zeros(B, self.Np, dtype=self.cd, device=dev)
+        self.AK = AK
         self.support = agent.atoms[0].contiguous()
+        self._gb2_pad = torch.zeros(self.Np, **f32)
         self.refresh_effective()
         self.refresh_target()
 
     # ---- effective weights ------------------------------------------------------------------------------
+    @staticmethod
+    def _store(dst_w, dst_b, w, b):
+        dst_w[:w.shape[0], :w.shape[1]].copy_(w)
+        dst_b[:b.shape[0]].copy_(b)
+
     @torch.no_grad()
     def refresh_effective(self):
         for (w_e, b_e), l in zip(self.eff, self.layers):
-            w, b = l.effective()
-            w_e.copy_(w)
-            b_e.copy_(b)
+            self._store(w_e, b_e, *l.effective())
 
     @torch.no_grad()
     def refresh_target(self):
         for (w_t, b_t), l in zip(self.trg, self.agent.target.layers):
-            w, b = l.effective()
-            w_t.copy_(w)
-            b_t.copy_(b)
+            self._store(w_t, b_t, *l.effective())
 
     # ---- the two halves of an update ----------------------------------------------------------------------
     def part1(self, indices, prios):
@@ -97,7 +105,8 @@ class FusedLearner:
         s = K.current_stream()
         K.check(L.hb_replay_gather(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
                                    K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), K.dptr(indices), B, self.L,
-                                   K.dptr(self.x), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew), K.dptr(self.term), s))
+                                   K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew),
+                                   K.dptr(self.term), s))
         (w1, b1), (w2, b2) = self.eff
         h = torch._addmm_activation(b1, self.x, w1, use_gelu=False)  # bias + ReLU in the GEMM epilogue, [2B, H]
         logits_on = torch.addmm(b2, h, w2)                          # [2B, A*K]
@@ -105,13 +114,14 @@ class FusedLearner:
         logits_t = torch.addmm(tb2, torch._addmm_activation(tb1, self.x[B:], tw1, use_gelu=False), tw2)
         K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), float(a.params.discount),
-                                   1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk,
+                                   1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
                                    K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
         hb, xb, dl = h[:B], self.x[:B], self.dlogits
-        self.g_w2.copy_(torch.mm(hb.t(), dl))
-        K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, dl.shape[1], K.dptr(self.g_b2), s))
+        self.g_w2.copy_(torch.mm(hb.t(), dl)[:, :self.AK])            # drop the padding columns
+        K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
+        self.g_b2.copy_(self._gb2_pad[:self.AK])
         dh = torch.ops.aten.threshold_backward(torch.mm(dl, w2.t()), hb, 0.0)
-        self.g_w1.copy_(torch.mm(xb.t(), dh))
+        self.g_w1.copy_(torch.mm(xb.t(), dh)[:self.L])                # drop the padding rows
         K.check(L.hb_colsum(K.dptr(dh), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         return self.td, self.w_is
 
@@ -128,7 +138,8 @@ class FusedLearner:
                 K.check(L.hb_noisy_adam(K.dptr(ps[0]), K.dptr(ps[1]), K.dptr(ps[2]), K.dptr(noise), K.dptr(g),
                                         K.dptr(st[0][0]), K.dptr(st[0][1]), K.dptr(st[1][0]), K.dptr(st[1][1]),
                                         K.dptr(st[2][0]), K.dptr(st[2][1]), K.dptr(self.step), K.dptr(eff), _DT[self.cd],
-                                        ps[0].numel(), float(p.learning_rate), 0.9, 0.999, 3.125e-5, s))
+                                        ps[0].numel(), ps[0].shape[-1], eff.shape[-1], float(p.learning_rate), 0.9,
+                                        0.999, 3.125e-5, s))
         self.step.add_(1.0)
 
     def loss(self):

@@ -174,6 +174,7 @@ class DQNAgent:
         self._fused = self.device.type == "cuda" and self.distributional
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
         self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
+        self._x_act = None          # persistent (padded) first-GEMM operand of the actor
         self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
         self.use_fused_learner = use_fused_learner
         self._draws = 0             # Philox draw counter of the fused sampler
@@ -201,8 +202,8 @@ class DQNAgent:
     def _effective_weights(self):
         """[(W [in,out], bias [out])] of the online net in the GEMM dtype; recomputed only after the weights
         or the noise changed (the reference's noise is frozen, App. C-2, so acting re-uses them all the time)."""
-        if self._fl is not None:
-            return self._fl.eff  # kept current by hb_noisy_adam after every update
+        if self._fused_learner() is not None:
+            return self._fl.eff  # padded GEMM operands, kept current by hb_noisy_adam after every update
         if self._eff_cache is None:
             cd = _DTYPES[self.params.compute_dtype]
             self._eff_cache = [tuple(t.to(cd).contiguous() for t in layer.effective()) for layer in self.online.layers]
@@ -218,7 +219,15 @@ class DQNAgent:
             self._eff_cache = None
         eff = self._effective_weights()
         cd = eff[0][0].dtype
-        x = ops.obs_cast(obs.contiguous(), cd) if (obs.dtype == torch.int8 and cd != torch.float32) else obs.to(cd)
+        kp = eff[0][0].shape[0]                     # first-layer K, possibly padded (FusedLearner keeps padded operands)
+        if obs.dtype == torch.int8 and cd != torch.float32:
+            if self._x_act is None or self._x_act.shape != (obs.shape[0], kp) or self._x_act.dtype != cd:
+                self._x_act = torch.zeros(obs.shape[0], kp, dtype=cd, device=self.device)   # pad columns stay zero
+            x = ops.obs_cast(obs.contiguous(), cd, out=self._x_act)
+        else:
+            x = obs.to(cd)
+            if kp != x.shape[1]:
+                x = torch.nn.functional.pad(x, (0, kp - x.shape[1]))
         for i, (w, b) in enumerate(eff):  # bias (+ ReLU) ride in the GEMM epilogue
             x = torch._addmm_activation(b, x, w, use_gelu=False) if i < len(eff) - 1 else torch.addmm(b, x, w)
         self._draws += 1

@@ -7,23 +7,27 @@ _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
 def policy_act(logits, legal, support, epsilon, seed, draw, first_game_id=0, actions_out=None, q_out=None):
-    """logits [N, A*K] (f32/bf16/f16, contiguous CUDA), legal [N, A] int8, support [K] f32 -> actions int32 [N]."""
+    """logits [N, >= A*K] (f32/bf16/f16, contiguous CUDA; extra columns are GEMM padding), legal [N, A] int8,
+    support [K] f32 -> actions int32 [N]."""
     n, a = legal.shape
     k = support.numel()
-    assert logits.is_cuda and logits.is_contiguous() and logits.shape == (n, a * k) and logits.dtype in _DT
+    assert logits.is_cuda and logits.is_contiguous() and logits.shape[0] == n and logits.shape[1] >= a * k and logits.dtype in _DT
     assert legal.dtype == torch.int8 and legal.is_contiguous() and support.dtype == torch.float32
     actions = actions_out if actions_out is not None else torch.empty(n, dtype=torch.int32, device=logits.device)
     K.check(K.lib().hb_policy_act(K.dptr(logits), _DT[logits.dtype], K.dptr(legal), K.dptr(support), n, a, k,
-                                  float(epsilon), int(seed), int(draw), int(first_game_id), K.dptr(actions), K.dptr(q_out),
+                                  logits.shape[1], float(epsilon), int(seed), int(draw), int(first_game_id), K.dptr(actions), K.dptr(q_out),
                                   K.current_stream()))
     return actions
 
 
 def obs_cast(obs, dtype, out=None):
-    """int8 0/1 [N, L] -> bf16 / f16 tensor of the same shape (one HBM pass)."""
+    """int8 0/1 [N, L] -> bf16 / f16 [N, >= L] (one HBM pass). `out` may be wider than L (K padding of the first
+    GEMM); its extra columns are not touched and must already be zero."""
     assert obs.dtype == torch.int8 and obs.is_cuda and obs.is_contiguous() and dtype in (torch.bfloat16, torch.float16)
     out = out if out is not None else torch.empty(obs.shape, dtype=dtype, device=obs.device)
-    K.check(K.lib().hb_obs_cast(K.dptr(obs), K.dptr(out), _DT[dtype], obs.numel(), K.current_stream()))
+    assert out.dtype == dtype and out.is_contiguous() and out.shape[0] == obs.shape[0] and out.shape[1] >= obs.shape[1]
+    K.check(K.lib().hb_obs_cast(K.dptr(obs), K.dptr(out), _DT[dtype], obs.shape[0], obs.shape[1], out.shape[1],
+                                K.current_stream()))
     return out
 
 

@@ -214,14 +214,17 @@ int hb_per_update(hb_tree* t, const int64_t* idx_dev, const float* td_dev, int64
  * epsilon-greedy sample (epsilon = 0: greedy with uniform tie-breaking). Randomness is
  * Philox4x32-10(seed; draw, first_game_id + g): word 0 -> explore decision, word 1 -> which
  * candidate. support_dev [n_atoms] f32; actions_dev [n] int32; q_dev [n, n_actions] f32 or
- * NULL (receives the UNMASKED q).                                                        */
+ * NULL (receives the UNMASKED q). row_stride >= n_actions*n_atoms: elements between logits
+ * rows (the second GEMM's N is padded 1020 -> 1024 because hipBLASLt is 1.4x faster there).  */
 int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* legal_dev, const float* support_dev,
-                  int64_t n_games, int32_t n_actions, int32_t n_atoms, float epsilon, uint64_t seed, uint64_t draw,
-                  int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream);
+                  int64_t n_games, int32_t n_actions, int32_t n_atoms, int32_t row_stride, float epsilon, uint64_t seed,
+                  uint64_t draw, int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream);
 
-/* int8 0/1 observation matrix -> 16-bit float GEMM operand (out_dtype 1 = bf16, 2 = f16),
- * 16 bytes in / 32 bytes out per lane; both pointers 16-byte aligned.                     */
-int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t n_elements, void* stream);
+/* int8 0/1 observation matrix [rows, cols] -> 16-bit float GEMM operand (out_dtype 1 = bf16,
+ * 2 = f16) whose rows are out_ld >= cols elements apart (K padded 658 -> 704: the first GEMM
+ * is 1.4x faster); padding columns are not written — zero them once.                       */
+int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t rows, int32_t cols, int32_t out_ld,
+                void* stream);
 
 /* ---- fused replay insert (hanabi_agents/rlax_dqn/rlax_rainbow.py:297-308 +
  *      experience_buffer.py:26-81 for a batch without FIRST rows) --------------------------
@@ -239,15 +242,15 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
  * dtype codes: 0 = f32, 1 = bf16, 2 = f16.
  *
  * hb_replay_gather: batch gather experience_buffer.py:83-87 straight into the GEMM operand:
- *   x_dev [2*batch, obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
+ *   x_dev [2*batch, x_ld >= obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
  *   act_dev [B] int32, rew_dev [B] f32, term_dev [B] f32 (0/1).                                */
 int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
                      const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
-                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t* act_dev, float* rew_dev, float* term_dev,
-                     void* stream);
+                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
+                     float* term_dev, void* stream);
 
 /* hb_c51_loss_grad: rlax_rainbow.py:172-200 on precomputed logits.
- *   logits_online_dev [2B, A*K]: rows 0..B-1 = online(obs_tm1), rows B..2B-1 = online(obs_t);
+ *   logits_online_dev [2B, row_stride >= A*K]: rows 0..B-1 = online(obs_tm1), rows B..2B-1 = online(obs_t);
  *   logits_target_dev [B, A*K] = target(obs_t); support_dev [K] uniform atoms.
  *   Outputs: td_dev [B] (cross-entropy "TD", its |.| is the new priority), w_dev [B] (IS
  *   weights (1/P)^beta / max), dlogits_dev [B, A*K] = d mean(td * w) / d online(obs_tm1).
@@ -255,7 +258,7 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
-                     int32_t n_atoms, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
+                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
 
 /* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:
  * the column sums of dLoss/dlogits and of dLoss/dhidden). x_dev [rows, cols] contiguous.        */
@@ -264,11 +267,12 @@ int hb_colsum(const void* x_dev, int32_t dtype, int64_t rows, int64_t cols, floa
 /* hb_noisy_adam: one Adam step (optix.adam form, rlax_rainbow.py:257) on the three parameters
  * behind one merged NoisyLinear tensor W = w + w_mu + w_sigma * noise (noisy_mlp.py:61-91), given
  * grad_dev = dLoss/dW (f32); writes the new merged tensor to eff_dev in eff_dtype. step_dev holds
- * the number of steps already taken (the caller increments it once per update).                */
+ * the number of steps already taken (the caller increments it once per update). The parameter tensors
+ * are [n/cols, cols] row-major; eff_dev rows are eff_ld >= cols elements apart (padded GEMM operand).      */
 int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float* noise_dev, const float* grad_dev,
                   float* m_w_dev, float* v_w_dev, float* m_mu_dev, float* v_mu_dev, float* m_sigma_dev, float* v_sigma_dev,
-                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, float lr, float beta1, float beta2,
-                  float eps, void* stream);
+                  const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, int32_t cols, int32_t eff_ld, float lr,
+                  float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,12 @@ def test_policy_q_values_and_greedy_choice(n, a, k, dtype):
     support = torch.linspace(-25, 25, k, device="cuda")
     q = torch.empty(n, a, device="cuda")
     act = ops.policy_act(logits, legal, support, 0.0, seed=7, draw=3, q_out=q)
+    # the same logits inside a wider, padded row (the second GEMM's N is padded to a multiple of 64)
+    wide = torch.full((n, (a * k + 63) // 64 * 64 + 64), 7.0, device="cuda", dtype=dt)
+    wide[:, :a * k] = logits
+    q_w = torch.empty(n, a, device="cuda")
+    act_w = ops.policy_act(wide, legal, support, 0.0, seed=7, draw=3, q_out=q_w)
+    assert torch.equal(act, act_w) and torch.equal(q, q_w)
     ref = L.expected_q(logits.float().view(n, a, k), support.repeat(a, 1))       # torch fp32 reference on the same inputs
     assert torch.allclose(q, ref, rtol=2e-5, atol=2e-6)
     masked = torch.where(legal.bool(), q, torch.full_like(q, float("-inf")))
@@ -226,4 +232,5 @@ def test_fused_learner_equals_autograd_learner(mask, priority):
         assert np.allclose(la, lb, rtol=2e-3)
     # the actor sees the freshly written effective weights
     w_eff, _ = fused.online.layers[0].effective()
-    assert torch.allclose(fused._effective_weights()[0][0].float(), w_eff, rtol=1e-2, atol=1e-3)
+    got = fused._effective_weights()[0][0].float()
+    assert torch.allclose(got[:obs_len], w_eff, rtol=1e-2, atol=1e-3) and not got[obs_len:].any()   # K padding stays zero
