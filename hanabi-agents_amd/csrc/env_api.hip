@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/hanabi_hip.h"
 #include "common.hpp"
@@ -59,7 +60,8 @@ struct hb_env {
   unsigned long long seed;
   long long first_gid;
   uint32_t* state;
-  unsigned long long* illegal;
+  unsigned long long* illegal;  // [0] illegal uids, then per-wavefront {episodes finished, sum of final scores}
+  long long stat_slots;
   uint8_t* next_deck;  // [n, 64] deck pool: the deck each game is dealt at its next (re)deal
   uint8_t* refill;     // [n] flags: pool entry consumed / stale
   const uint8_t* decks;
@@ -132,9 +134,10 @@ int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t 
   HB_HIP_OR(hipGetDevice(&e->device), delete e);
   const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
-  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->illegal), 8), { (void)hipFree(e->state); delete e; });
+  e->stat_slots = n_games / 16 + 8;  // one slot per wavefront at the smallest games-per-wave setting
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->illegal), 8 + 16 * e->stat_slots), { (void)hipFree(e->state); delete e; });
   HB_HIP_OR(hipMemset(e->state, 0, bytes), { hb_env_destroy(e); });
-  HB_HIP_OR(hipMemset(e->illegal, 0, 8), { hb_env_destroy(e); });
+  HB_HIP_OR(hipMemset(e->illegal, 0, 8 + 16 * e->stat_slots), { hb_env_destroy(e); });
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->next_deck), static_cast<size_t>(n_games) * hb::NEXT_DECK_BYTES), { hb_env_destroy(e); });
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->refill), static_cast<size_t>(n_games)), { hb_env_destroy(e); });
   HB_HIP_OR(hipMemset(e->next_deck, 0, static_cast<size_t>(n_games) * hb::NEXT_DECK_BYTES), { hb_env_destroy(e); });
@@ -190,6 +193,8 @@ static void fill_common(hb_env* e, hb::EnvArgs& a) {
   a.decks = e->decks;
   a.next_deck = e->next_deck;
   a.refill = e->refill;
+  a.illegal = e->illegal;
+  a.stats = e->illegal + 1;
   a.n = e->n;
   a.seed = e->seed;
   a.first_gid = e->first_gid;
@@ -232,6 +237,7 @@ static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.next_deck = e->next_deck;
   a.refill = e->refill;
   a.illegal = e->illegal;
+  a.stats = e->illegal + 1;
   a.n = e->n;
   a.seed = e->seed;
   a.first_gid = e->first_gid;
@@ -319,6 +325,17 @@ int hb_env_illegal_count(hb_env* e, int64_t* out) {
   unsigned long long v = 0;
   HB_HIP(hipMemcpy(&v, e->illegal, 8, hipMemcpyDeviceToHost));
   *out = static_cast<int64_t>(v);
+  return HB_OK;
+}
+
+int hb_env_stats(hb_env* e, int64_t* episodes, int64_t* score_sum) {
+  if (!e || !episodes || !score_sum) return fail(HB_ERR_INVALID, "null argument");
+  std::vector<unsigned long long> v(static_cast<size_t>(2 * e->stat_slots));
+  HB_HIP(hipMemcpy(v.data(), e->illegal + 1, 16 * e->stat_slots, hipMemcpyDeviceToHost));
+  unsigned long long ep = 0, sc = 0;
+  for (long long i = 0; i < e->stat_slots; ++i) { ep += v[2 * i]; sc += v[2 * i + 1]; }
+  *episodes = static_cast<int64_t>(ep);
+  *score_sum = static_cast<int64_t>(sc);
   return HB_OK;
 }
 

@@ -49,6 +49,7 @@ struct EnvArgs {
   int8_t* agent_step_type;
   int8_t* score;
   unsigned long long* illegal;
+  unsigned long long* stats;  // per-wavefront running totals [n/16 + 4][2]: episodes finished, sum of final scores
   long long n;
   unsigned long long seed;
   long long first_gid;
@@ -607,6 +608,19 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   if (mode == MODE_STEP) {
     const unsigned long long bad = __ballot(illegal);
     if (bad && lane == 0) atomicAdd(a.illegal, static_cast<unsigned long long>(__popcll(bad)));
+    // running episode statistics without atomics: every wavefront owns one slot (launches are stream-ordered, so
+    // the read-modify-write cannot race); thousands of same-address atomics per step cost ~12 ns each and showed
+    // up as +6 us on the kernel
+    const unsigned long long ended = __ballot(out_term != 0);
+    if (ended) {
+      int sc = out_term ? out_score : 0;
+      for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+      if (lane == 0) {
+        unsigned long long* slot = a.stats + 2 * (static_cast<long long>(blockIdx.x) * 4 + wave);
+        slot[0] += static_cast<unsigned long long>(__popcll(ended));
+        slot[1] += static_cast<unsigned long long>(sc);
+      }
+    }
   }
   HB_STAMP(6);
   wave_sync();

@@ -147,18 +147,25 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
 }
 
 // ---------------------------------------------------------------------------------------------
-// column sums out[j] = sum_i x[i, j] (bias gradients): 64 columns x 4 row groups per workgroup, fixed
-// summation order (deterministic), fp32 accumulation
+// column sums out[j] = sum_i x[i, j] (bias gradients): 64 columns x 16 row groups per workgroup, so a 256-row
+// operand is 16 independent loads per thread (one memory round trip); fixed summation order, fp32 accumulation
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, rg = threadIdx.x >> 6;
   float s = 0.f;
-  if (c < cols)
-    for (int i = rg; i < rows; i += 4) s += ld<T>(x, static_cast<long long>(i) * cols + c);
-  part[rg][threadIdx.x & 63] = s;
+  if (c < cols) {
+#pragma unroll 16
+    for (int i = rg; i < rows; i += 16) s += ld<T>(x, static_cast<long long>(i) * cols + c);
+  }
+  part[rg][l] = s;
   __syncthreads();
-  if (rg == 0 && c < cols) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rg == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][l];
+    out[c] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,7 +276,7 @@ int hb_colsum(const void* x_dev, int32_t dtype, int64_t rows, int64_t cols, floa
   if (!x_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
   if (rows <= 0 || cols <= 0) return HB_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>((cols + 63) / 64)), block(256);
+  const dim3 grid(static_cast<unsigned>((cols + 63) / 64)), block(1024);
   const int r = static_cast<int>(rows), c = static_cast<int>(cols);
   if (dtype == 0) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, static_cast<const float*>(x_dev), r, c, out_dev);
   else if (dtype == 1) hipLaunchKernelGGL((colsum_kernel<__hip_bfloat16>), grid, block, 0, s, static_cast<const __hip_bfloat16*>(x_dev), r, c, out_dev);

@@ -36,80 +36,67 @@ __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte access: one dwordx4 instruction on gfx950
 
-constexpr int MAX_WAVE_ELEMS = 64 * 64;  // LDS floats per wavefront: covers A*K <= 4096 per game group
 
-template <typename T>
+// Lane (game, action) owns one row of K atoms: it reads them straight from HBM with byte-aligned 16-byte loads
+// (K*sizeof(T) = 102 B rows for bf16: consecutive lanes read consecutive rows, every cache line is consumed whole
+// across the 7 loads of the wave), keeps them in registers and reduces softmax / expectation locally. No LDS
+// staging and no barrier: ~70 VGPRs -> 6 waves per SIMD, so the ~11 k wavefronts of a 32 768-game step cover
+// the chip in under two rounds (the LDS-staged form was limited to 3 workgroups per CU and took 48 us).
+template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logits, const int8_t* __restrict__ legal,
                                                      const float* __restrict__ support, long long n, int A, int K, int ld,
                                                      float epsilon, unsigned long long seed, unsigned long long draw,
                                                      long long first_gid, int32_t* __restrict__ actions,
                                                      float* __restrict__ q_out) {
-  extern __shared__ float lds[];
+  __shared__ float qlds[4][64];
+  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte load
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gpw = 64 / A;
-  const int per_wave = gpw * A * K;
-  float* buf = lds + wave * (per_wave + 64);
-  float* qbuf = buf + per_wave;
   const long long g0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * gpw;
   if (g0 >= n) return;
   const long long left = n - g0;
   const int ng = left < gpw ? static_cast<int>(left) : gpw;
-  const int elems = ng * A * K;
-  const T* src = logits + g0 * ld;
-  // stage HBM -> LDS: 4 elements per lane per load, FOUR independent loads in flight per lane before the first
-  // LDS write (a wave owns ~12 KB of logits; issuing the loads back-to-back hides the HBM latency once, not 12x).
-  // Rows are ld >= A*K elements apart (the GEMM output may be padded): element e of the wave's block lives at
-  // src[(e / AK) * ld + e % AK].
-  const int AK = A * K;
-  if ((AK & 3) == 0 && (ld & 3) == 0) {
-    for (int base = 0; base < elems; base += 1024) {
-      int e[4];
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        e[u] = base + u * 256 + lane * 4;
-        if (e[u] < elems) {
-          const int gq = e[u] / AK;
-          const T* p = src + static_cast<long long>(gq) * ld + (e[u] - gq * AK);
-          if constexpr (sizeof(T) == 4) {
-            v[u] = *reinterpret_cast<const float4*>(p);
-          } else {
-            const uint2 raw = *reinterpret_cast<const uint2*>(p);
-            const T* t = reinterpret_cast<const T*>(&raw);
-            v[u] = make_float4(to_f32<T>(t[0]), to_f32<T>(t[1]), to_f32<T>(t[2]), to_f32<T>(t[3]));
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (e[u] < elems) { buf[e[u]] = v[u].x; buf[e[u] + 1] = v[u].y; buf[e[u] + 2] = v[u].z; buf[e[u] + 3] = v[u].w; }
-    }
-  } else {
-    for (int e = lane; e < elems; e += 64) {
-      const int gq = e / AK;
-      buf[e] = to_f32<T>(src[static_cast<long long>(gq) * ld + (e - gq * AK)]);
-    }
-  }
-  hb::wave_sync();
   const int gw = lane / A, a = lane - gw * A;
   const bool on = gw < ng;
   float q = -INFINITY;
   bool is_legal = false;
   if (on) {
-    const float* row = buf + (gw * A + a) * K;
-    float m = row[0];
-    for (int k = 1; k < K; ++k) m = fmaxf(m, row[k]);
-    float s = 0.f, t = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float e = __expf(row[k] - m);
-      s += e;
-      t += e * support[k];
+    const T* row = logits + (g0 + gw) * ld + a * K;
+    const T* end = logits + n * static_cast<long long>(ld);  // one past the tensor: vector loads never cross it
+    float v[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX / VEC; ++c) {
+      if (c * VEC < K) {
+        const T* p = row + c * VEC;
+        if (p + VEC <= end) {
+          const u32x4 raw = *reinterpret_cast<const u32x4_u*>(p);
+          const T* t = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[c * VEC + j] = to_f32<T>(t[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[c * VEC + j] = (p + j < end) ? to_f32<T>(p[j]) : 0.f;
+        }
+      }
     }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) m = fmaxf(m, v[k]);
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        const float e = __expf(v[k] - m);
+        s += e;
+        t += e * support[k];
+      }
     const float qv = t / s / static_cast<float>(K);
     if (q_out) q_out[(g0 + gw) * A + a] = qv;
     is_legal = legal[(g0 + gw) * A + a] != 0;
     q = is_legal ? qv : -INFINITY;
   }
+  float* qbuf = qlds[wave];
   qbuf[lane] = q;
   hb::wave_sync();
   // per-game arg-max and candidate sets without touching memory again: every lane scans its game's A values
@@ -147,8 +134,7 @@ int launch_policy(const void* logits, const int8_t* legal, const float* support,
   const int gpw = 64 / A;
   const long long per_block = 4LL * gpw;
   const unsigned blocks = static_cast<unsigned>((n + per_block - 1) / per_block);
-  const size_t lds = 4 * (static_cast<size_t>(gpw) * A * K + 64) * sizeof(float);
-  hipLaunchKernelGGL((policy_kernel<T>), dim3(blocks), dim3(256), lds, s, static_cast<const T*>(logits), legal, support,
+  hipLaunchKernelGGL((policy_kernel<T, 64>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(logits), legal, support,
                      static_cast<long long>(n), A, K, ld, eps, static_cast<unsigned long long>(seed),
                      static_cast<unsigned long long>(draw), static_cast<long long>(first_gid), actions, q_out);
   HB_HIP(hipGetLastError());
@@ -284,12 +270,9 @@ int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* le
                   uint64_t draw, int64_t first_game_id, int32_t* actions_dev, float* q_dev, void* stream) {
   if (!logits_dev || !legal_dev || !support_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
-  if (n_atoms < 1 || (64 / n_actions) * n_actions * n_atoms > MAX_WAVE_ELEMS)
-    return fail(HB_ERR_INVALID, "n_actions * n_atoms too large for the LDS staging buffer");
+  if (n_atoms < 1 || n_atoms > 64) return fail(HB_ERR_INVALID, "n_atoms must be 1..64 (atoms are held in registers)");
   if (n_games <= 0) return HB_OK;
   if (row_stride < n_actions * n_atoms) return fail(HB_ERR_INVALID, "row_stride must be >= n_actions * n_atoms");
-  const int esz = logits_dtype == 0 ? 4 : 2;
-  if (reinterpret_cast<uintptr_t>(logits_dev) & (4 * esz - 1)) return fail(HB_ERR_ALIGN, "logits_dev must be 16-byte (fp32) / 8-byte (16-bit) aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (logits_dtype) {
     case 0: return launch_policy<float>(logits_dev, legal_dev, support_dev, n_games, n_actions, n_atoms, row_stride, epsilon, seed, draw, first_game_id, actions_dev, q_dev, s);

@@ -439,6 +439,7 @@ class DQNAgent:
         else:
             self.optimizer.step()
         if self.params.use_priority:
+            # (running this on a forked graph branch beside Adam was measured slower: 0.216 vs 0.190 ms per update)
             self.experience.update_priorities_dev(indices, new_prios)
 
     def _update_eager(self):

@@ -60,6 +60,7 @@ SIGNATURES = {
     "hb_env_observe": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "hb_env_step": (C.c_int, [_P] + [_P] * 8 + [_P]),
     "hb_env_illegal_count": (C.c_int, [_P, C.POINTER(_I64)]),
+    "hb_env_stats": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "hb_env_export_state": (C.c_int, [_P, _P, _P]),
     "hb_env_import_state": (C.c_int, [_P, _P, _P]),
     "hb_random_legal_actions": (C.c_int, [_P, _I64, _I32, _U64, _U64, _I64, _P, _P]),

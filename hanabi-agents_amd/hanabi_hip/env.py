@@ -121,6 +121,12 @@ class HanabiEnv:
         K.check(self.L.hb_env_illegal_count(self.h, C.byref(v)))
         return v.value
 
+    def stats(self):
+        """(episodes finished, sum of their final scores) since creation — accumulated inside the step kernel."""
+        ep, sc = C.c_int64(), C.c_int64()
+        K.check(self.L.hb_env_stats(self.h, C.byref(ep), C.byref(sc)))
+        return ep.value, sc.value
+
     def export_state(self):
         rows = torch.empty((self.n, self.state_words), dtype=torch.int32, device=self.device)
         K.check(self.L.hb_env_export_state(self.h, K.dptr(rows), K.current_stream()))

@@ -32,8 +32,7 @@ class SelfPlaySession:
         self.train_seats = set(range(env.players)) if train_seats is None else set(train_seats)
         self.env_steps = 0
         self.grad_steps = 0
-        self.episodes = torch.zeros((), dtype=torch.int64, device=env.device)
-        self.score_sum = torch.zeros((), dtype=torch.int64, device=env.device)
+        self._stats0 = env.stats()
 
     def step(self, train=True, explore=True):
         env = self.env
@@ -49,8 +48,6 @@ class SelfPlaySession:
         actions = agent.explore(observations) if explore else agent.exploit(observations)
         self.last_actions[seat] = actions
         env.step(actions)
-        self.episodes += env.terminal.sum()
-        self.score_sum += (env.score * env.terminal).sum()
         self.env_steps += env.n
         if train and seat in self.train_seats:
             need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
@@ -64,6 +61,12 @@ class SelfPlaySession:
         for _ in range(steps):
             self.step(train=train)
 
+    @property
+    def episodes(self):
+        """Episodes finished since this session started (counted inside the env kernel)."""
+        return self.env.stats()[0] - self._stats0[0]
+
     def mean_score(self):
-        e = int(self.episodes.item())
-        return float(self.score_sum.item()) / e if e else float("nan")
+        ep, sc = self.env.stats()
+        ep, sc = ep - self._stats0[0], sc - self._stats0[1]
+        return sc / ep if ep else float("nan")

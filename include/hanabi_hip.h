@@ -132,6 +132,10 @@ int hb_env_step(hb_env* env, const int32_t* actions_dev, int8_t* obs_dev, int8_t
 /* Number of illegal uids seen since creation (synchronises the stream).                */
 int hb_env_illegal_count(hb_env* env, int64_t* out);
 
+/* Running totals since creation: episodes finished and the sum of their final scores
+ * (accumulated inside hb_env_step; synchronises the stream).                             */
+int hb_env_stats(hb_env* env, int64_t* episodes, int64_t* score_sum);
+
 /* Raw state rows for differential tests: rows_dev is [n_games, hb_state_words()] u32.  */
 int hb_env_export_state(hb_env* env, uint32_t* rows_dev, void* stream);
 int hb_env_import_state(hb_env* env, const uint32_t* rows_dev, void* stream);

@@ -170,3 +170,15 @@ def test_unaligned_output_is_rejected():
     buf = torch.zeros(8 * 658 + 64, dtype=torch.int8, device="cuda")
     rc = K.lib().hb_env_observe(env.h, C.c_void_p(buf.data_ptr() + 1), K.dptr(env.legal), None, None, K.current_stream())
     assert rc == -4 and b"aligned" in K.lib().hb_last_error()
+
+
+def test_episode_statistics_counted_in_kernel():
+    env, orc = _pair("Hanabi-Small", 2, 300)
+    episodes = score = 0
+    for t in range(60):
+        act = env.random_legal_actions(seed=9, draw=t)
+        env.step(act)
+        out = orc.step(act.cpu().numpy())
+        episodes += int(out["terminal"].sum())
+        score += int((out["score"] * out["terminal"]).sum())
+    assert episodes > 100 and env.stats() == (episodes, score)
