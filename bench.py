@@ -58,6 +58,18 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(args):
     """Oracle env (step + legal + encode) on the host: same game config, Philox decks and random-legal
     policy; 1 thread and all cores. Bounded to ~10-30 s."""
@@ -65,7 +77,7 @@ def cpu_baseline(args):
 
     n, steps = args.cpu_sample_games, args.cpu_sample_steps
     flags = O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     out = {}
     for label, threads in (("1", 1), ("all", cores)):
         env = O.OracleEnv(O.make_config("Hanabi-Full", args.players, flags), n, seed=1234, threads=threads)
