@@ -608,17 +608,17 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   if (mode == MODE_STEP) {
     const unsigned long long bad = __ballot(illegal);
     if (bad && lane == 0) atomicAdd(a.illegal, static_cast<unsigned long long>(__popcll(bad)));
-    // running episode statistics without atomics: every wavefront owns one slot (launches are stream-ordered, so
-    // the read-modify-write cannot race); thousands of same-address atomics per step cost ~12 ns each and showed
-    // up as +6 us on the kernel
+    // running episode statistics: every wavefront owns one slot, so the no-return atomics never contend (thousands
+    // of atomics on ONE address cost ~12 ns each and showed up as +6 us on the kernel; a plain load-add-store
+    // would put a dependent HBM round trip at the very end of the wave)
     const unsigned long long ended = __ballot(out_term != 0);
     if (ended) {
       int sc = out_term ? out_score : 0;
       for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
       if (lane == 0) {
         unsigned long long* slot = a.stats + 2 * (static_cast<long long>(blockIdx.x) * 4 + wave);
-        slot[0] += static_cast<unsigned long long>(__popcll(ended));
-        slot[1] += static_cast<unsigned long long>(sc);
+        atomicAdd(slot, static_cast<unsigned long long>(__popcll(ended)));
+        atomicAdd(slot + 1, static_cast<unsigned long long>(sc));
       }
     }
   }

@@ -18,6 +18,8 @@
 
 #include "../../include/hanabi_hip.h"
 #include "common.hpp"
+#include <type_traits>
+
 #include "env_kernel.hpp"  // philox4x32_10
 
 using hb::fail;
@@ -37,52 +39,64 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte access: one dwordx4 instruction on gfx950
 
 
-// Lane (game, action) owns one row of K atoms: it reads them straight from HBM with byte-aligned 16-byte loads
-// (K*sizeof(T) = 102 B rows for bf16: consecutive lanes read consecutive rows, every cache line is consumed whole
-// across the 7 loads of the wave), keeps them in registers and reduces softmax / expectation locally. No LDS
-// staging and no barrier: ~70 VGPRs -> 6 waves per SIMD, so the ~11 k wavefronts of a 32 768-game step cover
-// the chip in under two rounds (the LDS-staged form was limited to 3 workgroups per CU and took 48 us).
+// A wavefront owns gpw = 64 / A consecutive games. Their logits (gpw rows of A*K elements, rows `ld` apart) are
+// fetched with fully coalesced 4-element loads — ALL of a lane's loads are issued before the first LDS write, so
+// the HBM latency is paid once — and parked in LDS in their 16-bit form (6 KB per wave for 3 x 20 x 51 bf16:
+// 6 workgroups per CU). Lane (game, action) then reduces its K atoms from LDS (softmax, expectation).
 template <typename T, int KMAX>
 __global__ __launch_bounds__(256) void policy_kernel(const T* __restrict__ logits, const int8_t* __restrict__ legal,
                                                      const float* __restrict__ support, long long n, int A, int K, int ld,
                                                      float epsilon, unsigned long long seed, unsigned long long draw,
                                                      long long first_gid, int32_t* __restrict__ actions,
                                                      float* __restrict__ q_out) {
+  extern __shared__ unsigned char lds_raw[];
   __shared__ float qlds[4][64];
-  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte load
+  typedef typename std::conditional<sizeof(T) == 4, uint4, uint2>::type chunk_t;  // 4 elements
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gpw = 64 / A;
+  const int AK = A * K;
+  const int per_wave = (gpw * AK + 3) & ~3;
+  T* buf = reinterpret_cast<T*>(lds_raw) + wave * per_wave;
   const long long g0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * gpw;
   if (g0 >= n) return;
   const long long left = n - g0;
   const int ng = left < gpw ? static_cast<int>(left) : gpw;
+  const int elems = ng * AK;
+  const T* src = logits + g0 * ld;
+  if ((AK & 3) == 0 && (ld & 3) == 0) {
+    chunk_t r[16];  // up to 4096 elements per wavefront
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = (u * 64 + lane) * 4;
+      if (e < elems) {
+        const int gq = e / AK;
+        r[u] = *reinterpret_cast<const chunk_t*>(src + static_cast<long long>(gq) * ld + (e - gq * AK));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = (u * 64 + lane) * 4;
+      if (e < elems) *reinterpret_cast<chunk_t*>(buf + e) = r[u];
+    }
+  } else {
+    for (int e = lane; e < elems; e += 64) {
+      const int gq = e / AK;
+      buf[e] = src[static_cast<long long>(gq) * ld + (e - gq * AK)];
+    }
+  }
+  hb::wave_sync();
   const int gw = lane / A, a = lane - gw * A;
   const bool on = gw < ng;
   float q = -INFINITY;
   bool is_legal = false;
   if (on) {
-    const T* row = logits + (g0 + gw) * ld + a * K;
-    const T* end = logits + n * static_cast<long long>(ld);  // one past the tensor: vector loads never cross it
+    const T* row = buf + (gw * A + a) * K;
     float v[KMAX];
 #pragma unroll
-    for (int c = 0; c < KMAX / VEC; ++c) {
-      if (c * VEC < K) {
-        const T* p = row + c * VEC;
-        if (p + VEC <= end) {
-          const u32x4 raw = *reinterpret_cast<const u32x4_u*>(p);
-          const T* t = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) v[c * VEC + j] = to_f32<T>(t[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) v[c * VEC + j] = (p + j < end) ? to_f32<T>(p[j]) : 0.f;
-        }
-      }
-    }
+    for (int k = 0; k < KMAX; ++k) v[k] = k < K ? to_f32<T>(row[k]) : -INFINITY;
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) m = fmaxf(m, v[k]);
+    for (int k = 0; k < KMAX; ++k) m = fmaxf(m, v[k]);
     float s = 0.f, t = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
@@ -134,7 +148,8 @@ int launch_policy(const void* logits, const int8_t* legal, const float* support,
   const int gpw = 64 / A;
   const long long per_block = 4LL * gpw;
   const unsigned blocks = static_cast<unsigned>((n + per_block - 1) / per_block);
-  hipLaunchKernelGGL((policy_kernel<T, 64>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(logits), legal, support,
+  const size_t lds = 4 * static_cast<size_t>((gpw * A * K + 3) & ~3) * sizeof(T);
+  hipLaunchKernelGGL((policy_kernel<T, 64>), dim3(blocks), dim3(256), lds, s, static_cast<const T*>(logits), legal, support,
                      static_cast<long long>(n), A, K, ld, eps, static_cast<unsigned long long>(seed),
                      static_cast<unsigned long long>(draw), static_cast<long long>(first_gid), actions, q_out);
   HB_HIP(hipGetLastError());
@@ -271,6 +286,8 @@ int hb_policy_act(const void* logits_dev, int32_t logits_dtype, const int8_t* le
   if (!logits_dev || !legal_dev || !support_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
   if (n_atoms < 1 || n_atoms > 64) return fail(HB_ERR_INVALID, "n_atoms must be 1..64 (atoms are held in registers)");
+  if ((64 / n_actions) * n_actions * n_atoms > 4096) return fail(HB_ERR_INVALID, "n_actions * n_atoms too large for the staging buffer");
+  if (reinterpret_cast<uintptr_t>(logits_dev) & 15) return fail(HB_ERR_ALIGN, "logits_dev must be 16-byte aligned");
   if (n_games <= 0) return HB_OK;
   if (row_stride < n_actions * n_atoms) return fail(HB_ERR_INVALID, "row_stride must be >= n_actions * n_atoms");
   hipStream_t s = static_cast<hipStream_t>(stream);
