@@ -124,6 +124,8 @@ def main():
         params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
                            params._replace(seed=1234 + 17 * s), device=device) for s in range(args.players)]
+        for a in agents:
+            a.first_game_id = rank * n  # keys the exploration RNG by global game id
         if world > 1:  # identical initial weights on every rank (data parallel)
             for a in agents:
                 for t in list(a.online.parameters()) + list(a.online.buffers()):
