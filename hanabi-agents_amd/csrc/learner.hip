@@ -45,23 +45,57 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// n-step assembly at SAMPLE time (spec: hanabi_agents/rainbow/replay_memory.py:316-345). The ring
+// holds 1-step transitions of one seat; when every insert appends the same number of rows (n_ins = games, the
+// lock-step driver), the seat's next transition of the same game sits n_ins slots further on. Starting at the
+// sampled slot the chain follows up to n_step-1 successors, stops at an episode end or at the write pointer,
+// and returns R = sum gamma^k r_k, the final obs_t / terminal flag and disc = gamma^m (m = steps taken).
+struct NStep {
+  const long long* size_wp;  // device: {entries in the ring, next slot to be written}
+  long long cap, n_ins;
+  int n_step;
+  float gamma;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(const int8_t* __restrict__ ring_tm1, const int8_t* __restrict__ ring_t,
                                                      const int8_t* __restrict__ ring_act, const float* __restrict__ ring_rew,
                                                      const uint8_t* __restrict__ ring_term, const int64_t* __restrict__ idx,
                                                      int B, int L, T* __restrict__ x, int x_ld, int32_t* __restrict__ act,
-                                                     float* __restrict__ rew, float* __restrict__ term) {
+                                                     float* __restrict__ rew, float* __restrict__ term,
+                                                     float* __restrict__ disc, const NStep ns) {
+  __shared__ long long s_slot;
   const int r = blockIdx.x;  // output row 0..2B-1
   const int b = r < B ? r : r - B;
-  const long long slot = idx[b];
+  long long slot = idx[b];
+  if (r >= B) {  // obs_t row: walk the n-step chain (one thread, a handful of dependent 1-byte / 4-byte reads)
+    if (threadIdx.x == 0) {
+      long long j = slot;
+      float R = ring_rew[j], g = ns.gamma;
+      int m = 1;
+      if (ns.n_step > 1) {
+        const long long size = ns.size_wp[0], wp = ns.size_wp[1];
+        const long long ahead = size >= ns.cap ? ((wp - 1 - slot) % ns.cap + ns.cap) % ns.cap : size - 1 - slot;
+        while (m < ns.n_step && !ring_term[j] && static_cast<long long>(m) * ns.n_ins <= ahead) {
+          j = (j + ns.n_ins) % ns.cap;
+          R += g * ring_rew[j];
+          g *= ns.gamma;
+          ++m;
+        }
+      }
+      rew[b] = R;
+      term[b] = ring_term[j] ? 1.f : 0.f;
+      disc[b] = g;
+      s_slot = j;
+    }
+    __syncthreads();
+    slot = s_slot;
+  } else if (threadIdx.x == 0) {
+    act[b] = ring_act[slot];
+  }
   const int8_t* src = (r < B ? ring_tm1 : ring_t) + slot * L;
   T* dst = x + static_cast<long long>(r) * x_ld;  // row stride x_ld >= L: padding columns are left untouched (zero)
   for (int j = threadIdx.x; j < L; j += 256) st<T>(dst, j, static_cast<float>(src[j]));
-  if (r < B && threadIdx.x == 0) {
-    act[b] = ring_act[slot];
-    rew[b] = ring_rew[slot];
-    term[b] = ring_term[slot] ? 1.f : 0.f;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -70,7 +104,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_on, const T* __restrict__ logits_t,
                                                   const int32_t* __restrict__ act, const float* __restrict__ rew,
                                                   const float* __restrict__ term, const double* __restrict__ prios,
-                                                  const float* __restrict__ beta_dev, float discount, int mask_terminal,
+                                                  const float* __restrict__ beta_dev, const float* __restrict__ disc, int mask_terminal,
                                                   const float* __restrict__ support, int B, int A, int K, int rs,
                                                   float* __restrict__ td_out, float* __restrict__ w_out,
                                                   T* __restrict__ dlogits) {
@@ -116,7 +150,7 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   const float p = et / wave_sum(et);
   const float vmin = support[0], vmax = support[K - 1];
   const float delta = (vmax - vmin) / static_cast<float>(K - 1);
-  float gamma = discount;
+  float gamma = disc[b];  // gamma^m of this sample's (n-step) transition
   if (mask_terminal) gamma *= 1.f - term[b];
   const float zi = atom ? support[lane] : 0.f;
   const float tz = fminf(fmaxf(rew[b] + gamma * zi, vmin), vmax);  // clipped r + gamma * z_j held by lane j
@@ -224,21 +258,26 @@ extern "C" {
 int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
                      const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
                      int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
-                     float* term_dev, void* stream) {
+                     float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert,
+                     const int64_t* size_wp_dev, void* stream) {
   if (!ring_obs_tm1_dev || !ring_obs_t_dev || !ring_act_dev || !ring_rew_dev || !ring_term_dev || !idx_dev || !x_dev ||
-      !act_dev || !rew_dev || !term_dev)
+      !act_dev || !rew_dev || !term_dev || !disc_dev)
     return fail(HB_ERR_INVALID, "null argument");
   if (batch <= 0) return HB_OK;
   if (x_ld < obs_len) return fail(HB_ERR_INVALID, "x_ld must be >= obs_len");
+  if (n_step < 1) return fail(HB_ERR_INVALID, "n_step must be >= 1");
+  if (n_step > 1 && (!size_wp_dev || rows_per_insert < 1 || capacity < 1))
+    return fail(HB_ERR_INVALID, "n_step > 1 needs size_wp_dev, rows_per_insert and capacity");
+  const NStep ns{reinterpret_cast<const long long*>(size_wp_dev), capacity, rows_per_insert, n_step, gamma};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(2 * batch)), block(256);
   const int B = static_cast<int>(batch);
   if (x_dtype == 0)
-    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
   else if (x_dtype == 1)
-    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
   else if (x_dtype == 2)
-    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), x_ld, act_dev, rew_dev, term_dev);
+    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
   else
     return fail(HB_ERR_INVALID, "x_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
@@ -247,9 +286,9 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
 
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
-                     float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
+                     const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream) {
-  if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev ||
+  if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev || !disc_dev ||
       !support_dev || !td_dev || !w_dev || !dlogits_dev)
     return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64 || n_atoms < 2 || n_atoms > 64) return fail(HB_ERR_INVALID, "need n_actions <= 64 and 2 <= n_atoms <= 64");
@@ -261,7 +300,7 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
   const int B = static_cast<int>(batch);
 #define HB_C51(T)                                                                                                       \
   hipLaunchKernelGGL((c51_kernel<T>), grid, block, lds, s, static_cast<const T*>(logits_online_dev),                    \
-                     static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, discount, \
+                     static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, disc_dev, \
                      mask_terminal, support_dev, B, n_actions, n_atoms, row_stride, td_dev, w_dev, static_cast<T*>(dlogits_dev))
   if (dtype == 0) HB_C51(float);
   else if (dtype == 1) HB_C51(__hip_bfloat16);

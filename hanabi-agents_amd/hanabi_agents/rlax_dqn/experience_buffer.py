@@ -42,6 +42,8 @@ class ExperienceBuffer:
         self.size = 0
         self._gen = torch.Generator(device=d).manual_seed(seed)
         self._size_t = torch.zeros((), dtype=torch.float64, device=d)
+        self._size_wp = torch.zeros(2, dtype=torch.int64, device=d)   # {size, write pointer} for the n-step gather
+        self.rows_per_insert = None   # constant batch size of all inserts so far (None: nothing yet, -1: it varied)
 
     # ---- ring arithmetic (experience_buffer.py:21-24,46-81) ---------------------------------------
     def get_update_indices(self, batch_size):
@@ -52,6 +54,10 @@ class ExperienceBuffer:
 
     def _advance(self, batch_size):
         """Returns the list of (buffer slice, batch slice) pairs and moves oldest_entry/size."""
+        if self.rows_per_insert is None:
+            self.rows_per_insert = batch_size
+        elif self.rows_per_insert != batch_size:
+            self.rows_per_insert = -1
         start = self.oldest_entry
         if start + batch_size <= self.capacity:
             parts = [(slice(start, start + batch_size), slice(0, batch_size))]
@@ -116,8 +122,38 @@ class ExperienceBuffer:
         return torch.randint(0, self.size, (batch_size,), device=self.device, generator=self._gen)
 
     def sync_size(self):
-        """Publish the host-side `size` to the device scalar used by sample_indices_dev."""
+        """Publish the host-side `size` / write pointer to the device scalars read inside captured graphs."""
         self._size_t.fill_(float(self.size))
+        self._size_wp[0] = self.size
+        self._size_wp[1] = self.oldest_entry
+
+    def gather_nstep_dev(self, indices: torch.Tensor, n_step: int, gamma: float):
+        """n-step transitions assembled at sample time (PyTorch reference of hb_replay_gather's chain walk).
+
+        Valid when every insert appended `rows_per_insert` rows (lock-step self-play): the same seat's next
+        transition of the same game sits rows_per_insert slots further on. Follows up to n_step-1 successors,
+        stopping at an episode end or at the write pointer. Returns (Transition, discount [B] = gamma^m)."""
+        if n_step > 1 and (self.rows_per_insert is None or self.rows_per_insert < 1):
+            raise ValueError("n_step > 1 needs inserts of a constant row count")
+        cap, n_ins = self.capacity, self.rows_per_insert or 1
+        j = indices.clone()
+        rew = self._rew_t_buf[j, 0].clone()
+        disc = torch.full_like(rew, gamma)
+        alive = torch.ones_like(j, dtype=torch.bool)
+        if self.size >= cap:
+            ahead = (self.oldest_entry - 1 - indices) % cap
+        else:
+            ahead = self.size - 1 - indices
+        for m in range(1, n_step):
+            alive = alive & ~self._terminal_t_buf[j, 0] & (m * n_ins <= ahead)
+            nxt = (j + n_ins) % cap
+            j = torch.where(alive, nxt, j)
+            rew = torch.where(alive, rew + disc * self._rew_t_buf[j, 0], rew)
+            disc = torch.where(alive, disc * gamma, disc)
+        t = Transition(self._obs_tm1_buf.index_select(0, indices), self._act_tm1_buf.index_select(0, indices),
+                       rew[:, None], self._obs_t_buf.index_select(0, j), self._lms_t_buf.index_select(0, j),
+                       self._terminal_t_buf.index_select(0, j))
+        return t, disc
 
     def sample_dev(self, batch_size: int) -> Transition:
         return self.gather_dev(self.sample_indices_dev(batch_size))

@@ -72,6 +72,7 @@ class FusedLearner:
         self.act = torch.empty(B, dtype=torch.int32, device=dev)
         self.rew = torch.empty(B, **f32)
         self.term = torch.empty(B, **f32)
+        self.disc = torch.empty(B, **f32)
         self.td = torch.empty(B, **f32)
         self.w_is = torch.empty(B, **f32)
         self.dlogits = torch.zeros(B, self.Np, dtype=self.cd, device=dev)
@@ -102,18 +103,21 @@ class FusedLearner:
         """Forward, loss, backward into flat_grad. indices int64 [B], prios float64 [B] (device)."""
         a, L = self.agent, K.lib()
         buf, B = a.experience, self.B
+        if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
+            raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         s = K.current_stream()
         K.check(L.hb_replay_gather(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
                                    K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), K.dptr(indices), B, self.L,
                                    K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew),
-                                   K.dptr(self.term), s))
+                                   K.dptr(self.term), K.dptr(self.disc), int(a.params.n_step), float(a.params.discount),
+                                   buf.capacity, int(buf.rows_per_insert or 1), K.dptr(buf._size_wp), s))
         (w1, b1), (w2, b2) = self.eff
         h = torch._addmm_activation(b1, self.x, w1, use_gelu=False)  # bias + ReLU in the GEMM epilogue, [2B, H]
         logits_on = torch.addmm(b2, h, w2)                          # [2B, A*K]
         (tw1, tb1), (tw2, tb2) = self.trg
         logits_t = torch.addmm(tb2, torch._addmm_activation(tb1, self.x[B:], tw1, use_gelu=False), tw2)
         K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
-                                   K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), float(a.params.discount),
+                                   K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
                                    1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
                                    K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
         hb, xb, dl = h[:B], self.x[:B], self.dlogits

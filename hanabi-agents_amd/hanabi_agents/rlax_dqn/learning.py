@@ -43,7 +43,8 @@ def expected_q(logits: torch.Tensor, atoms: torch.Tensor) -> torch.Tensor:
 def categorical_double_q_td(logits_tm1, a_tm1, r_t, discount, atoms, logits_t, logits_sel, terminal_t=None):
     """Per-sample C51 double-Q cross-entropy 'TD error' (rlax_rainbow.py:172-185).
 
-    logits_* [B, A, K]; a_tm1 [B] int64; r_t [B]; atoms [A, K] (rows identical); discount scalar.
+    logits_* [B, A, K]; a_tm1 [B] int64; r_t [B]; atoms [A, K] (rows identical); discount scalar (the reference)
+    or a [B] tensor (gamma^m per sample, n-step).
     terminal_t: None reproduces the reference (bootstraps through episode ends, App. C-5);
     a [B] 0/1 tensor multiplies the discount by (1 - terminal).
     """
@@ -53,7 +54,10 @@ def categorical_double_q_td(logits_tm1, a_tm1, r_t, discount, atoms, logits_t, l
     q_sel = expected_q(logits_sel, atoms)                        # no legal-move mask, as in the reference
     a_star = torch.argmax(q_sel, dim=-1)
     p_target = F.softmax(logits_t[ar, a_star], dim=-1)           # [B, K]
-    disc = torch.full((b,), float(discount), dtype=r_t.dtype, device=r_t.device)  # (a fill kernel: graph-capturable)
+    if isinstance(discount, torch.Tensor):  # per-sample gamma^m of n-step transitions
+        disc = discount.to(r_t.dtype)
+    else:
+        disc = torch.full((b,), float(discount), dtype=r_t.dtype, device=r_t.device)  # (a fill kernel: graph-capturable)
     if terminal_t is not None:
         disc = disc * (1.0 - terminal_t.to(r_t.dtype))
     target_z = r_t[:, None] + disc[:, None] * support[None, :]

@@ -34,6 +34,8 @@ class RlaxRainbowParams(NamedTuple):
     resample_noise: bool = False             # True: fresh NoisyLinear noise every call (reference noise is frozen, C-2)
     compute_dtype: str = "float32"           # "float32" | "bfloat16" | "float16": GEMM input dtype, fp32 accumulate/master
     distributional: bool = True              # False: scalar double-DQN head (rlax_dqn.py:170-205 spec, BASELINE config 2)
+    n_step: int = 1                          # >1: n-step returns assembled at sample time (rainbow/replay_memory.py:316-345 spec);
+                                             #     needs inserts of a constant row count (the lock-step self-play driver)
 
 
 try:  # optional: same registration the reference performs (params.py:4)

@@ -175,6 +175,7 @@ class DQNAgent:
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
         self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
         self._x_act = None          # persistent (padded) first-GEMM operand of the actor
+        self._disc = params.discount  # scalar gamma, or the [B] tensor gamma^m of the current n-step batch
         self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
         self.use_fused_learner = use_fused_learner
         self._draws = 0             # Philox draw counter of the fused sampler
@@ -307,12 +308,12 @@ class DQNAgent:
 
     # ---- learning (rlax_rainbow.py:310-339) -----------------------------------------------------------------
     def _sample(self):
-        b = self.params.train_batch_size
-        if self.params.use_priority:
-            return self.experience.sample_batch_dev(b)
-        indices = self.experience.sample_indices_dev(b)
-        prios = torch.ones(b, dtype=torch.float64, device=self.device)  # rlax_rainbow.py:318-319
-        return indices, prios, self.experience.gather_dev(indices)
+        indices, prios = self._sample_indices()
+        if self.params.n_step > 1:
+            tr, self._disc = self.experience.gather_nstep_dev(indices, self.params.n_step, self.params.discount)
+        else:
+            tr, self._disc = self.experience.gather_dev(indices), self.params.discount
+        return indices, prios, tr
 
     def update(self):
         """Make one training step."""
@@ -386,7 +387,7 @@ class DQNAgent:
             logits_t = ht.float().view(b, a, k)
         term = tr.terminal_t[:, 0]
         td = L.categorical_double_q_td(logits_on[:b], tr.action_tm1[:, 0].long(), tr.reward_t[:, 0].to(torch.float32),
-                                       self.params.discount, self.atoms, logits_t, logits_on[b:].detach(),
+                                       self._disc, self.atoms, logits_t, logits_on[b:].detach(),
                                        term if self.params.mask_terminal else None)
         w_is = L.is_weights(prios, self._beta)
         return torch.mean(td * w_is), torch.abs(td).detach()
@@ -427,7 +428,7 @@ class DQNAgent:
         else:
             tr = tr._replace(observation_tm1=self._net_input(tr.observation_tm1),
                              observation_t=self._net_input(tr.observation_t))
-            loss, new_prios = DQNLearning.loss(self.online, self.target, self.atoms, tr, self.params.discount, prios,
+            loss, new_prios = DQNLearning.loss(self.online, self.target, self.atoms, tr, self._disc, prios,
                                                self._beta, self.params.mask_terminal, self.distributional)
         self._flat_grad.zero_()
         loss.backward()  # every p.grad is a view into _flat_grad: gradients accumulate in place

@@ -247,21 +247,27 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
  *
  * hb_replay_gather: batch gather experience_buffer.py:83-87 straight into the GEMM operand:
  *   x_dev [2*batch, x_ld >= obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
- *   act_dev [B] int32, rew_dev [B] f32, term_dev [B] f32 (0/1).                                */
+ *   act_dev [B] int32, rew_dev [B] f32, term_dev [B] f32 (0/1), disc_dev [B] f32 = gamma^m.
+ * n_step > 1 assembles n-step transitions at sample time (spec: hanabi_agents/rainbow/replay_memory.py:316-345):
+ * the seat's next transition of the same game is rows_per_insert slots further on; the chain stops at an episode
+ * end or at the ring's write pointer (size_wp_dev = {entries, next slot to write}, device int64[2]);
+ * rew = sum gamma^k r_k, obs_t / term from the last step, disc = gamma^m. n_step = 1 is the reference.      */
 int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
                      const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
                      int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
-                     float* term_dev, void* stream);
+                     float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert,
+                     const int64_t* size_wp_dev, void* stream);
 
 /* hb_c51_loss_grad: rlax_rainbow.py:172-200 on precomputed logits.
  *   logits_online_dev [2B, row_stride >= A*K]: rows 0..B-1 = online(obs_tm1), rows B..2B-1 = online(obs_t);
  *   logits_target_dev [B, A*K] = target(obs_t); support_dev [K] uniform atoms.
  *   Outputs: td_dev [B] (cross-entropy "TD", its |.| is the new priority), w_dev [B] (IS
  *   weights (1/P)^beta / max), dlogits_dev [B, A*K] = d mean(td * w) / d online(obs_tm1).
+ *   disc_dev [B]: per-sample discount (gamma for 1-step, gamma^m for n-step transitions).
  *   mask_terminal != 0 multiplies the discount by (1 - term) (off = the reference, App. C-5).   */
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
-                     float discount, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
+                     const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
 
 /* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:

@@ -186,8 +186,8 @@ def test_batched_gpu_loss_equals_reference_loss_and_gradient():
             assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-7 + 2e-4 * float(gb.abs().max()))  # fp32 GEMMs of different M: summation order
 
 
-@pytest.mark.parametrize("mask,priority", [(False, False), (True, False), (True, True)])
-def test_fused_learner_equals_autograd_learner(mask, priority):
+@pytest.mark.parametrize("mask,priority,n_step", [(False, False, 1), (True, False, 1), (True, True, 1), (True, False, 3)])
+def test_fused_learner_equals_autograd_learner(mask, priority, n_step):
     """FusedLearner (hb_replay_gather + hb_c51_loss_grad + hand-written backward + hb_noisy_adam) against the
     PyTorch-autograd fp32 reference path (DQNLearning.loss + torch.optim.Adam) on the same batches."""
     import torch
@@ -195,8 +195,8 @@ def test_fused_learner_equals_autograd_learner(mask, priority):
     from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
 
     n, obs_len, n_act = 256, 658, 20
-    params = RlaxRainbowParams(use_priority=priority, train_batch_size=256, experience_buffer_size=256, target_update_period=3,
-                               mask_terminal=mask)
+    params = RlaxRainbowParams(use_priority=priority, train_batch_size=256, experience_buffer_size=256 * n_step,
+                               target_update_period=3, mask_terminal=mask, n_step=n_step)
     agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False,
                        use_fused_learner=f) for f in (True, False)]
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -212,12 +212,14 @@ def test_fused_learner_equals_autograd_learner(mask, priority):
                 layer.b_sigma.fill_(0.05)
         a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
         a.add_experience((None, (o2, legal)), act, rew, st)
+        for extra in range(n_step - 1):   # further dense inserts so that n-step chains have successors
+            a.add_experience_dense((None, (o1 if extra % 2 else o2, legal)), act, rew + extra, st)
         a.target.load_state_dict(a.online.state_dict())
     idx = torch.randperm(n, device="cuda", generator=g)
     pri = (torch.rand(n, device="cuda", generator=g, dtype=torch.float64) + 0.05) / n
     fused, ref = agents
     fused._sample_indices = lambda: (idx, pri)
-    ref._sample = lambda: (idx, pri, ref.experience.gather_dev(idx))
+    ref._sample_indices = lambda: (idx, pri)
     for step in range(5):
         fused.update()
         ref.update()

@@ -72,3 +72,42 @@ def test_priority_buffer_matches_reference_golden_on_gpu():
             assert buf.max_priority == pytest.approx(step["max_priority"], rel=2e-7)
             assert buf.min_priority == pytest.approx(step["min_priority"], rel=2e-7)
             assert np.allclose(buf.sum_tree.get_values(range(case["tree_capacity"])), step["leaves_after_update"], rtol=2e-7, atol=0)
+
+
+def _nstep_reference(rew, term, n_ins, cap, size, wp, i, n, gamma):
+    """Plain-Python n-step walk (hanabi_agents/rainbow/replay_memory.py:316-345 semantics on our ring)."""
+    ahead = (wp - 1 - i) % cap if size >= cap else size - 1 - i
+    j, R, g, m = i, rew[i], gamma, 1
+    while m < n and not term[j] and m * n_ins <= ahead:
+        j = (j + n_ins) % cap
+        R += g * rew[j]
+        g *= gamma
+        m += 1
+    return j, R, g
+
+
+@pytest.mark.parametrize("cap,n_ins,inserts", [(40, 8, 3), (40, 8, 5), (40, 8, 11), (37, 5, 20)])
+def test_nstep_gather_matches_python_walk(cap, n_ins, inserts):
+    import torch
+
+    rng = np.random.default_rng(cap + inserts)
+    buf = ExperienceBuffer(6, 3, 1, cap, device="cpu")
+    for k in range(inserts):
+        buf.add_transitions(rng.integers(0, 2, (n_ins, 6)), rng.integers(0, 3, (n_ins, 1)), rng.integers(-2, 3, (n_ins, 1)).astype(float),
+                            np.full((n_ins, 6), k % 2), np.ones((n_ins, 3)), rng.random((n_ins, 1)) < 0.25)
+    assert buf.rows_per_insert == n_ins
+    rew = buf._rew_t_buf[:, 0].numpy().astype(np.float64)
+    term = buf._terminal_t_buf[:, 0].numpy()
+    idx = torch.arange(buf.size)
+    for n in (1, 2, 3, 5):
+        tr, disc = buf.gather_nstep_dev(idx, n, 0.9)
+        for i in range(buf.size):
+            j, R, g = _nstep_reference(rew, term, n_ins, cap, buf.size, buf.oldest_entry, i, n, 0.9)
+            assert tr.reward_t[i, 0].item() == pytest.approx(R, rel=1e-6, abs=1e-6)
+            assert disc[i].item() == pytest.approx(g, rel=1e-6)
+            assert bool(tr.terminal_t[i, 0]) == bool(term[j])
+            assert torch.equal(tr.observation_t[i], buf._obs_t_buf[j]) and torch.equal(tr.observation_tm1[i], buf._obs_tm1_buf[i])
+    buf.add_transitions(np.zeros((3, 6)), np.zeros((3, 1)), np.zeros((3, 1)), np.zeros((3, 6)), np.ones((3, 3)), np.zeros((3, 1), bool))
+    assert buf.rows_per_insert == -1
+    with pytest.raises(ValueError):
+        buf.gather_nstep_dev(idx[:4], 3, 0.9)
