@@ -165,6 +165,7 @@ class DQNAgent:
         buf = PriorityBuffer if params.use_priority else ExperienceBuffer
         self.experience = buf(obs_len, self.n_actions, 1, params.experience_buffer_size, device=self.device,
                               seed=params.seed)
+        self.experience.track_wp = params.n_step > 1
         # the reference keeps last_obs as float64 [N, obs_len] (172 MB at 32k games, C-13); int8 here
         self.last_obs = torch.zeros((n_games, obs_len), dtype=torch.int8, device=self.device)
         self.requires_vectorized_observation = lambda: True
