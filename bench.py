@@ -146,6 +146,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if session is not None:
+        session.flush()
 
     # live per-dispatch timing of the env kernel inside the timed region
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -161,6 +163,8 @@ def main():
     for k in range(args.steps):
         env.set_profile_events(*ev[k])
         one_step()
+    if session is not None:
+        session.flush()  # the last update's Adam / priority half (deferred behind the all-reduce when data-parallel)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

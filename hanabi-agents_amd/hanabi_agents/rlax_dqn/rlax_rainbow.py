@@ -176,6 +176,7 @@ class DQNAgent:
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
         self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
         self._x_act = None          # persistent (padded) first-GEMM operand of the actor
+        self._pending = None          # (all-reduce handle, eager part-2 arguments) between update_begin / update_finish
         self._disc = params.discount  # scalar gamma, or the [B] tensor gamma^m of the current n-step batch
         self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
         self.use_fused_learner = use_fused_learner
@@ -318,11 +319,38 @@ class DQNAgent:
 
     def update(self):
         """Make one training step."""
+        self.update_begin()
+        self.update_finish()
+
+    # Two-phase form of update() for data-parallel runs: update_begin() samples, computes the loss gradient into
+    # the flat buffer and STARTS the RCCL all-reduce without blocking; update_finish() waits for it and applies
+    # Adam / priorities / target sync. A driver that alternates agents (hanabi_hip.selfplay) runs the next seat's
+    # replay insert, policy and env step between the two calls, so the ~3.4 MB gradient exchange over xGMI hides
+    # behind ~0.2 ms of independent work. With one rank the pair is exactly update().
+    def update_begin(self):
+        assert self._pending is None, "update_finish() of the previous update has not been called"
         self.experience.sync_size()
+        self._beta.fill_(float(self.params.beta_is(self.train_step)))
         if self._graphs_enabled():
-            self._update_graphed()
+            if self._graph1 is None:
+                self._capture_update_graphs()
+            self._graph1.replay()
+            part2_args = None
         else:
-            self._update_eager()
+            self.last_loss, indices, new_prios = self._update_part1()
+            part2_args = (indices, new_prios)
+        self._pending = (self._allreduce_gradients(async_op=True), part2_args)
+
+    def update_finish(self):
+        if self._pending is None:
+            return
+        work, part2_args = self._pending
+        self._pending = None
+        self._finish_allreduce(work)
+        if part2_args is None:
+            self._graph2.replay()
+        else:
+            self._update_part2(*part2_args)
         self._eff_cache = None
         if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
             self._sync_target()
@@ -445,21 +473,12 @@ class DQNAgent:
             self.experience.update_priorities_dev(indices, new_prios)
 
     def _update_eager(self):
-        self._beta.fill_(float(self.params.beta_is(self.train_step)))
         self.last_loss, indices, new_prios = self._update_part1()
-        self._allreduce_gradients()
+        self._finish_allreduce(self._allreduce_gradients(async_op=False))
         self._update_part2(indices, new_prios)
 
     def _graphs_enabled(self):
         return self.use_graphs and self.device.type == "cuda"
-
-    def _update_graphed(self):
-        self._beta.fill_(float(self.params.beta_is(self.train_step)))
-        if self._graph1 is None:
-            self._capture_update_graphs()
-        self._graph1.replay()
-        self._allreduce_gradients()
-        self._graph2.replay()
 
     def _capture_update_graphs(self):
         cur = torch.cuda.current_stream()
@@ -467,9 +486,7 @@ class DQNAgent:
         side.wait_stream(cur)
         with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, cuBLAS-like workspaces, Adam state)
             for _ in range(3):
-                _, idx, pr = self._update_part1()
-                self._allreduce_gradients()
-                self._update_part2(idx, pr)
+                self._update_eager()
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -478,17 +495,33 @@ class DQNAgent:
         with torch.cuda.graph(self._graph2, pool=self._graph1.pool()):
             self._update_part2(self._g_idx, self._g_prios)
 
-    def _allreduce_gradients(self):
-        """Data parallelism: ONE all-reduce (average) of the flat fp32 gradient over RCCL."""
+    def _dp_world(self):
         import torch.distributed as dist
 
         if self.process_group is None and not (dist.is_available() and dist.is_initialized()):
-            return
-        world = dist.get_world_size(self.process_group)
+            return 1
+        return dist.get_world_size(self.process_group)
+
+    def _allreduce_gradients(self, async_op=False):
+        """Data parallelism: ONE all-reduce (sum) of the flat fp32 gradient over RCCL. Returns the
+        torch.distributed Work handle when async_op (None with a single rank)."""
+        import torch.distributed as dist
+
+        if self._dp_world() == 1:
+            return None
+        flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        if not async_op:
+            work.wait()
+        return work
+
+    def _finish_allreduce(self, work):
+        world = self._dp_world()
         if world == 1:
             return
+        if work is not None:
+            work.wait()  # orders the current stream after the collective; does not block the host on NCCL/RCCL
         flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
         flat /= world
 
     # ---- misc --------------------------------------------------------------------------------------------

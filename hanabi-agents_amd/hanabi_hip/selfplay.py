@@ -21,7 +21,7 @@ import torch
 
 
 class SelfPlaySession:
-    def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None):
+    def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -30,8 +30,14 @@ class SelfPlaySession:
         self.last_actions = [torch.zeros(env.n, dtype=torch.int32, device=env.device) for _ in agents]
         self.min_replay = min_replay
         self.train_seats = set(range(env.players)) if train_seats is None else set(train_seats)
+        if overlap_allreduce is None:  # only worth the reordering when there is a collective to hide
+            import torch.distributed as dist
+
+            overlap_allreduce = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.overlap_allreduce = bool(overlap_allreduce) and len(set(map(id, agents))) == len(agents)
         self.env_steps = 0
         self.grad_steps = 0
+        self._inflight = None  # agent whose update_begin() has run but not its update_finish() (data-parallel overlap)
         self._stats0 = env.stats()
 
     def step(self, train=True, explore=True):
@@ -49,17 +55,33 @@ class SelfPlaySession:
         self.last_actions[seat] = actions
         env.step(actions)
         self.env_steps += env.n
+        # The previous seat's gradient all-reduce has been running behind this seat's insert / policy / env step:
+        # apply it now. (An agent always finishes its update before it acts again: seats alternate.)
+        if self._inflight is not None:
+            self._inflight.update_finish()
+            self._inflight = None
         if train and seat in self.train_seats:
             need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
             if agent.experience.size >= need:
-                for _ in range(self.updates_per_step):
-                    agent.update()
+                for k in range(self.updates_per_step):
+                    agent.update_begin()
                     self.grad_steps += 1
+                    if k + 1 < self.updates_per_step or not self.overlap_allreduce or env.players == 1:
+                        agent.update_finish()
+                    else:
+                        self._inflight = agent
         self.t += 1
+
+    def flush(self):
+        """Complete an update left in flight by the last step()."""
+        if self._inflight is not None:
+            self._inflight.update_finish()
+            self._inflight = None
 
     def run(self, steps, train=True):
         for _ in range(steps):
             self.step(train=train)
+        self.flush()
 
     @property
     def episodes(self):

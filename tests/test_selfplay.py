@@ -6,7 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_selfplay_transitions_match_oracle_replay():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_selfplay_transitions_match_oracle_replay(overlap):
     import torch
 
     import hanabi_hip
@@ -21,7 +22,7 @@ def test_selfplay_transitions_match_oracle_replay():
     params = RlaxRainbowParams(train_batch_size=32, experience_buffer_size=n * steps, layers=[32], mask_terminal=True)
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
               for s in (1, 2)]
-    sess = SelfPlaySession(env, agents, updates_per_step=1)
+    sess = SelfPlaySession(env, agents, updates_per_step=1, overlap_allreduce=overlap)  # overlap: update_finish one step later
     # oracle-side bookkeeping of what each seat's replay must contain
     last_obs = [None, None]
     last_act = [None, None]
@@ -43,7 +44,8 @@ def test_selfplay_transitions_match_oracle_replay():
         last_act[seat] = a.copy()
         out = orc.step(a)
         assert np.array_equal(env.obs.cpu().numpy(), out["obs"])
-    assert env.illegal_count() == 0
+    sess.flush()
+    assert env.illegal_count() == 0 and all(a._pending is None for a in agents)
     for seat in (0, 1):
         buf = agents[seat].experience
         k = len(want[seat])
