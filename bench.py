@@ -165,6 +165,7 @@ def main():
         one_step()
     if session is not None:
         session.flush()  # the last update's Adam / priority half (deferred behind the all-reduce when data-parallel)
+    host_enqueue_s = time.perf_counter() - t0  # host-side launch time of the timed region (GPU still draining)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -201,6 +202,7 @@ def main():
             "parallelism": f"dp{world}: games sharded, RCCL gradient all-reduce",
         },
         "grad_steps_per_sec": world * 0 + (grad_steps / dt if grad_steps else 0.0),
+        "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
         "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n,

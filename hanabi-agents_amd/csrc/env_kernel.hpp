@@ -209,7 +209,7 @@ __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride
           o.y = spread4(v[u] >> 4);
           o.z = spread4(v[u] >> 8);
           o.w = spread4(v[u] >> 12);
-          *reinterpret_cast<u32x4_unaligned*>(out + off[u]) = o;
+          __builtin_nontemporal_store(o, reinterpret_cast<u32x4_unaligned*>(out + off[u]));
         }
       }
     }

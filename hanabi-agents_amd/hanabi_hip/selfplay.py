@@ -21,7 +21,8 @@ import torch
 
 
 class SelfPlaySession:
-    def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None):
+    def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
+                 learner_stream=True):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -35,6 +36,14 @@ class SelfPlaySession:
 
             overlap_allreduce = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.overlap_allreduce = bool(overlap_allreduce) and len(set(map(id, agents))) == len(agents)
+        # Learner stream: seat A's update only has to finish before A acts again, so it is enqueued on a second HIP
+        # stream right after A's policy forward and runs beside the env step and the NEXT seat's insert / policy /
+        # env step (big GEMMs on the main stream, the ~30 small learner kernels on the side). Every dependency of the
+        # sequential order is kept by events, so results are identical to running everything on one stream.
+        self.learner_stream = None
+        if learner_stream and env.device.type == "cuda" and len(set(map(id, agents))) == len(agents) and len(agents) > 1:
+            self.learner_stream = torch.cuda.Stream(device=env.device)
+        self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
         self.env_steps = 0
         self.grad_steps = 0
         self._inflight = None  # agent whose update_begin() has run but not its update_finish() (data-parallel overlap)
@@ -44,6 +53,9 @@ class SelfPlaySession:
         env = self.env
         seat = self.t % env.players
         agent = self.agents[seat]
+        main = torch.cuda.current_stream() if self.learner_stream is not None else None
+        if main is not None and id(agent) in self._update_done:
+            main.wait_event(self._update_done.pop(id(agent)))  # its replay / weights are being written by that update
         observations = (None, (env.obs, env.legal))
         if self.t < env.players:
             # only during the first round can a seat be without a pending move (step type FIRST)
@@ -53,30 +65,53 @@ class SelfPlaySession:
             agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
         actions = agent.explore(observations) if explore else agent.exploit(observations)
         self.last_actions[seat] = actions
+        acted = None
+        if main is not None:
+            acted = torch.cuda.Event()
+            acted.record(main)  # the policy has read the weights: the learner may overwrite them from here on
         env.step(actions)
         self.env_steps += env.n
+        if self.learner_stream is None:
+            self._train_inline(agent, seat, train)
+        elif train and seat in self.train_seats and self._ready(agent):
+            with torch.cuda.stream(self.learner_stream):
+                self.learner_stream.wait_event(acted)
+                for _ in range(self.updates_per_step):
+                    agent.update_begin()
+                    agent.update_finish()
+                    self.grad_steps += 1
+                done = torch.cuda.Event()
+                done.record(self.learner_stream)
+            self._update_done[id(agent)] = done
+        self.t += 1
+
+    def _ready(self, agent):
+        need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
+        return agent.experience.size >= need
+
+    def _train_inline(self, agent, seat, train):
         # The previous seat's gradient all-reduce has been running behind this seat's insert / policy / env step:
         # apply it now. (An agent always finishes its update before it acts again: seats alternate.)
         if self._inflight is not None:
             self._inflight.update_finish()
             self._inflight = None
-        if train and seat in self.train_seats:
-            need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
-            if agent.experience.size >= need:
-                for k in range(self.updates_per_step):
-                    agent.update_begin()
-                    self.grad_steps += 1
-                    if k + 1 < self.updates_per_step or not self.overlap_allreduce or env.players == 1:
-                        agent.update_finish()
-                    else:
-                        self._inflight = agent
-        self.t += 1
+        if train and seat in self.train_seats and self._ready(agent):
+            for k in range(self.updates_per_step):
+                agent.update_begin()
+                self.grad_steps += 1
+                if k + 1 < self.updates_per_step or not self.overlap_allreduce or self.env.players == 1:
+                    agent.update_finish()
+                else:
+                    self._inflight = agent
 
     def flush(self):
-        """Complete an update left in flight by the last step()."""
+        """Complete an update left in flight by the last step() and rejoin the learner stream."""
         if self._inflight is not None:
             self._inflight.update_finish()
             self._inflight = None
+        if self.learner_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.learner_stream)
+            self._update_done.clear()
 
     def run(self, steps, train=True):
         for _ in range(steps):

@@ -6,8 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_selfplay_transitions_match_oracle_replay(overlap):
+@pytest.mark.parametrize("overlap,lstream", [(False, False), (True, False), (False, True)])
+def test_selfplay_transitions_match_oracle_replay(overlap, lstream):
     import torch
 
     import hanabi_hip
@@ -22,7 +22,7 @@ def test_selfplay_transitions_match_oracle_replay(overlap):
     params = RlaxRainbowParams(train_batch_size=32, experience_buffer_size=n * steps, layers=[32], mask_terminal=True)
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
               for s in (1, 2)]
-    sess = SelfPlaySession(env, agents, updates_per_step=1, overlap_allreduce=overlap)  # overlap: update_finish one step later
+    sess = SelfPlaySession(env, agents, updates_per_step=1, overlap_allreduce=overlap, learner_stream=lstream)  # overlap: update_finish one step later
     # oracle-side bookkeeping of what each seat's replay must contain
     last_obs = [None, None]
     last_act = [None, None]
@@ -92,3 +92,31 @@ def test_other_configs_run_end_to_end(game, players, kwargs):
         assert torch.isfinite(a.last_loss).item()
         assert a.experience.size > 0
     assert int(env.current_player()[0]) == (6 * players) % players and bool((env.current_player() == env.current_player()[0]).all())
+
+
+def test_learner_stream_gives_identical_training():
+    """Running the updates on the second stream keeps every dependency of the sequential order: two sessions
+    with the same seeds end with identical weights and replay contents."""
+    import torch
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    def run(lstream):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+        env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=256, seed=5)
+        params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=4096, mask_terminal=True, target_update_period=7)
+        agents = [DQNAgent(ObservationSpec((256, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda",
+                           use_graphs=False) for s in (1, 2)]
+        sess = SelfPlaySession(env, agents, learner_stream=lstream)
+        sess.run(40)
+        torch.cuda.synchronize()
+        return [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]) for a in agents], env.export_state()
+
+    (w_a, st_a), (w_b, st_b) = run(False), run(True)
+    assert torch.equal(st_a, st_b)
+    for x, y in zip(w_a, w_b):
+        assert torch.equal(x, y)
