@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--cpu-sample-games", type=int, default=4096)
     ap.add_argument("--cpu-sample-steps", type=int, default=150)
     ap.add_argument("--env-only", action="store_true", help="random-legal policy, no agents (kernel-only rate)")
+    ap.add_argument("--learner-cus", type=int, default=0,
+                    help="reserve this many CUs for the learner stream (CU-masked streams); 0 = no partition")
+    ap.add_argument("--no-learner-stream", action="store_true", help="run the updates in order on the main stream")
+    ap.add_argument("--learner-priority", type=int, default=-1, help="HIP stream priority of the learner stream (-1 = high)")
     return ap.parse_args()
 
 
@@ -120,6 +124,7 @@ def main():
 
     agents = []
     session = None
+    main_stream = None
     if not args.env_only:
         params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
@@ -131,10 +136,20 @@ def main():
                 for t in list(a.online.parameters()) + list(a.online.buffers()):
                     dist.broadcast(t.data, 0)
                 a.target.load_state_dict(a.online.state_dict())
-        session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step)
+        lstream = not args.no_learner_stream
+        if args.learner_cus > 0 and lstream:
+            from hanabi_hip.streams import masked_stream
+
+            lstream = masked_stream(0, args.learner_cus, device)
+            main_stream = masked_stream(args.learner_cus, 256, device)
+        session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_stream=lstream,
+                                  learner_priority=args.learner_priority)
 
     act = torch.empty(n, dtype=torch.int32, device=device)
     draw = [0]
+    if main_stream is not None:
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
 
     def one_step():
         if session is not None:

@@ -22,7 +22,7 @@ import torch
 
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
-                 learner_stream=True):
+                 learner_stream=True, learner_priority=-1):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -42,7 +42,9 @@ class SelfPlaySession:
         # sequential order is kept by events, so results are identical to running everything on one stream.
         self.learner_stream = None
         if learner_stream and env.device.type == "cuda" and len(set(map(id, agents))) == len(agents) and len(agents) > 1:
-            self.learner_stream = torch.cuda.Stream(device=env.device)
+            # (a torch.cuda.Stream / ExternalStream may be passed in, e.g. one restricted to a CU subset: streams.py)
+            self.learner_stream = learner_stream if isinstance(learner_stream, torch.cuda.Stream) else torch.cuda.Stream(
+                device=env.device, priority=learner_priority)
         self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
         self.env_steps = 0
         self.grad_steps = 0
