@@ -309,114 +309,103 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       keep_seats = false;
       reset_start = a.start_player;
     } else if (mode == MODE_STEP && ((w0 >> 19) & 3) == 0) {
-      int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7;
+      // The four move types are evaluated WITHOUT divergent branches: every effect is computed under a 0/1
+      // predicate and selected in. (The branchy form spent ~60 % of this phase's instructions on exec-mask
+      // bookkeeping and register copies at the joins.)
+      const int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7;
       const int s = (w0 >> 13) & 7;
-      int turns = (w0 >> 16) & 7, moves = (w0 >> 21) & 255;
-      const int uid = uid_in;
-      int type = MV_PLAY, ci = 0, toff = 0, hcol = 0, hrank = 0;
-      bool ok = uid >= 0 && uid < K::A;
-      if (uid < H) { type = MV_DISCARD; ci = uid; }
-      else if (uid < 2 * H) { type = MV_PLAY; ci = uid - H; }
-      else if (uid < 2 * H + (P - 1) * C) { const int x = uid - 2 * H; type = MV_RCOLOR; toff = 1 + x / C; hcol = x % C; }
-      else { const int x = uid - 2 * H - (P - 1) * C; type = MV_RRANK; toff = 1 + x / R; hrank = x % R; }
-      int n_s = hand_n(s);
-      uint32_t hs = row[K::W_HANDS + s];
+      const int turns = (w0 >> 16) & 7, moves = (w0 >> 21) & 255;
+      const bool in_range = uid_in >= 0 && uid_in < K::A;
+      const int uid = in_range ? uid_in : 0;  // an out-of-range uid is rejected below; keep every derived index in bounds
+      const bool is_discard = uid < H, is_play = uid >= H && uid < 2 * H;
+      const bool is_rc = uid >= 2 * H && uid < 2 * H + (P - 1) * C, is_rr = uid >= 2 * H + (P - 1) * C;
+      const bool card_move = is_discard || is_play, is_hint = !card_move;
+      const int type = is_play ? MV_PLAY : (is_discard ? MV_DISCARD : (is_rc ? MV_RCOLOR : MV_RRANK));
+      const int xc = uid - 2 * H, xr = uid - 2 * H - (P - 1) * C;
+      const int ci = is_discard ? uid : (is_play ? uid - H : 0);
+      const int toff = is_rc ? 1 + xc / C : (is_rr ? 1 + xr / R : 0);
+      const int hcol = is_rc ? xc % C : 0, hrank = is_rr ? xr % R : 0;
       int t = s + toff;
       if (t >= P) t -= P;
+      const int n_s = hand_n(s), n_t = hand_n(t);
+      const uint32_t hs = row[K::W_HANDS + s], ht = row[K::W_HANDS + t];
+      const uint64_t kn_s = (static_cast<uint64_t>(row[K::W_KNOW + 2 * s + 1]) << 32) | row[K::W_KNOW + 2 * s];
+      const uint64_t kn_t = (static_cast<uint64_t>(row[K::W_KNOW + 2 * t + 1]) << 32) | row[K::W_KNOW + 2 * t];
+      const uint8_t* deckb = reinterpret_cast<const uint8_t*>(row + K::W_DECK);
+      const uint32_t card_new = deckb[deck_size > 0 ? K::D - deck_size : 0];
+      // cards of the target hand that the hint touches
       uint32_t match = 0;
-      if (ok) {
-        if (type == MV_DISCARD) ok = info < K::INFO && ci < n_s;
-        else if (type == MV_PLAY) ok = ci < n_s;
-        else {
-          const uint32_t ht = row[K::W_HANDS + t];
-          const int n_t = hand_n(t);
 #pragma unroll
-          for (int i = 0; i < H; ++i) {
-            const int card = (ht >> (5 * i)) & 31;
-            const bool m = type == MV_RCOLOR ? (card / R == hcol) : (card % R == hrank);
-            if (i < n_t && m) match |= 1u << i;
-          }
-          ok = info > 0 && match != 0;
-        }
+      for (int i = 0; i < H; ++i) {
+        const int card = (ht >> (5 * i)) & 31;
+        const bool m = is_rc ? (card / R == hcol) : (card % R == hrank);
+        match |= static_cast<uint32_t>(is_hint && i < n_t && m) << i;
       }
-      if (!ok) {
-        illegal = true;
-      } else {
+      const bool ok = in_range && (is_discard ? (info < K::INFO && ci < n_s) : (is_play ? ci < n_s : (info > 0 && match != 0)));
+      illegal = !ok;
+      // ---- card moves: discard / play slot ci of the mover's hand
+      const int card = (hs >> (5 * ci)) & 31;
+      const int c_col = card / R, c_rank = card % R;
+      const bool success = is_play && fw(c_col < C ? c_col : 0) == c_rank && c_col < C;
+      const bool fail = is_play && !success;
+      const bool stack_done = success && c_rank == R - 1;
+      const int la_info = ((is_discard || stack_done) && info < K::INFO) ? 1 : 0;
+      const bool to_discard = is_discard || fail;
+      const uint32_t lowm = (1u << (5 * ci)) - 1u;
+      uint32_t hs_new = (hs & lowm) | ((hs >> (5 * (ci + 1))) << (5 * ci)) | (31u << 20);
+      const uint64_t klow = (1ull << (12 * ci)) - 1ull;
+      uint64_t kn_s_new = (kn_s & klow) | ((kn_s >> (12 * (ci + 1))) << (12 * ci));
+      const bool draws = deck_size > 0;  // replacement deal (A.5 step 6): only the mover's hand can be short
+      const int slot_new = n_s > 0 ? n_s - 1 : 0;
+      if (draws) {
+        hs_new = (hs_new & ~(31u << (5 * slot_new))) | (card_new << (5 * slot_new));
+        kn_s_new |= static_cast<uint64_t>(K::ALL_PLAUSIBLE) << (12 * slot_new);
+      }
+      // ---- hints: knowledge of every card in the target hand
+      uint64_t kn_t_new = kn_t;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const bool m = (match >> i) & 1u;
+        uint64_t k = (kn_t >> (12 * i)) & 0xFFFull;
+        const uint64_t k_rc = m ? ((k & ~0x1Full) | (1ull << hcol) | (1ull << 10)) : (k & ~(1ull << hcol));
+        const uint64_t k_rr = m ? ((k & ~(0x1Full << 5)) | (1ull << (5 + hrank)) | (1ull << 11)) : (k & ~(1ull << (5 + hrank)));
+        k = is_rc ? k_rc : k_rr;
+        if (i < n_t) kn_t_new = (kn_t_new & ~(0xFFFull << (12 * i))) | (k << (12 * i));
+      }
+      if (ok) {
+        // one pair of LDS stores for whichever hand changed (the mover's cards, or the target's knowledge)
+        const int pw = card_move ? s : t;
+        const uint64_t kn_w = card_move ? kn_s_new : kn_t_new;
+        if (card_move) row[K::W_HANDS + s] = hs_new;
+        row[K::W_KNOW + 2 * pw] = static_cast<uint32_t>(kn_w);
+        row[K::W_KNOW + 2 * pw + 1] = static_cast<uint32_t>(kn_w >> 32);
         // per-seat bookkeeping: this seat now has an open transition
         w3 = (w3 | (1u << s)) & ~(1u << (5 + s));
         accw &= ~(0xFFull << (8 * s));
         const int before = score_now();
-        if (deck_size == 0) --turns;
-        int la_color = 0, la_rank = 0, la_scored = 0, la_info = 0;
-        if (type == MV_DISCARD || type == MV_PLAY) {
-          const int card = (hs >> (5 * ci)) & 31;
-          la_color = card / R;
-          la_rank = card % R;
-          bool to_discard = true;
-          if (type == MV_DISCARD) {
-            la_info = info < K::INFO;
-            info += la_info;
-          } else if (fw(la_color) == la_rank) {
-            w1 += 1u << (3 * la_color);
-            la_scored = 1;
-            to_discard = false;
-            if (la_rank == R - 1) { la_info = info < K::INFO; info += la_info; }
-          } else {
-            --life;
-          }
-          if (to_discard) disc += 1ull << (2 * card);
-          // remove slot ci: cards and knowledge shift left, last slot becomes empty
-          const uint32_t lowm = (1u << (5 * ci)) - 1u;
-          hs = (hs & lowm) | ((hs >> (5 * (ci + 1))) << (5 * ci)) | (31u << 20);
-          uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * s + 1]) << 32) | row[K::W_KNOW + 2 * s];
-          const uint64_t klow = (1ull << (12 * ci)) - 1ull;
-          kn = (kn & klow) | ((kn >> (12 * (ci + 1))) << (12 * ci));
-          --n_s;
-          if (deck_size > 0) {  // replacement deal (A.5 step 6): only the mover's hand can be short
-            const uint8_t* deckb = reinterpret_cast<const uint8_t*>(row + K::W_DECK);
-            const uint32_t card_new = deckb[K::D - deck_size];
-            hs = (hs & ~(31u << (5 * n_s))) | (card_new << (5 * n_s));
-            kn |= static_cast<uint64_t>(K::ALL_PLAUSIBLE) << (12 * n_s);
-            ++n_s;
-            --deck_size;
-          }
-          row[K::W_HANDS + s] = hs;
-          row[K::W_KNOW + 2 * s] = static_cast<uint32_t>(kn);
-          row[K::W_KNOW + 2 * s + 1] = static_cast<uint32_t>(kn >> 32);
-          w1 = (w1 & ~(7u << (15 + 3 * s))) | (static_cast<uint32_t>(n_s) << (15 + 3 * s));
-        } else {
-          --info;
-          uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * t + 1]) << 32) | row[K::W_KNOW + 2 * t];
-          const int n_t = hand_n(t);
-#pragma unroll
-          for (int i = 0; i < H; ++i) {
-            if (i < n_t) {
-              const bool m = (match >> i) & 1u;
-              uint64_t k = (kn >> (12 * i)) & 0xFFFull;
-              if (type == MV_RCOLOR) k = m ? ((k & ~0x1Full) | (1ull << hcol) | (1ull << 10)) : (k & ~(1ull << hcol));
-              else k = m ? ((k & ~(0x1Full << 5)) | (1ull << (5 + hrank)) | (1ull << 11)) : (k & ~(1ull << (5 + hrank)));
-              kn = (kn & ~(0xFFFull << (12 * i))) | (k << (12 * i));
-            }
-          }
-          row[K::W_KNOW + 2 * t] = static_cast<uint32_t>(kn);
-          row[K::W_KNOW + 2 * t + 1] = static_cast<uint32_t>(kn >> 32);
-          if (type == MV_RCOLOR) la_color = hcol; else la_rank = hrank;
-        }
+        const int n_s_after = card_move ? (draws ? n_s : n_s - 1) : n_s;
+        w1 = (w1 & ~(7u << (15 + 3 * s))) | (static_cast<uint32_t>(n_s_after) << (15 + 3 * s));
+        if (success) w1 += 1u << (3 * c_col);
+        if (to_discard) disc += 1ull << (2 * card);
+        const int info2 = info + (card_move ? la_info : -1);
+        const int life2 = life - (fail ? 1 : 0);
+        const int deck2 = deck_size - ((card_move && draws) ? 1 : 0);
+        const int turns2 = turns - (deck_size == 0 ? 1 : 0);
+        const int la_color = card_move ? c_col : hcol, la_rank = card_move ? c_rank : hrank;
         w2 = 1u | (static_cast<uint32_t>(s) << 1) | (static_cast<uint32_t>(type) << 4) | (static_cast<uint32_t>(ci) << 6) |
              (static_cast<uint32_t>(toff) << 9) | (static_cast<uint32_t>(la_color) << 12) |
-             (static_cast<uint32_t>(la_rank) << 15) | (static_cast<uint32_t>(la_scored) << 18) |
-             (static_cast<uint32_t>(la_info) << 19) | (match << 20);
-        ++moves;
+             (static_cast<uint32_t>(la_rank) << 15) | (static_cast<uint32_t>(success ? 1 : 0) << 18) |
+             (static_cast<uint32_t>(card_move ? la_info : 0) << 19) | (match << 20);
         int cur = s + 1;
         if (cur >= P) cur = 0;
-        w0 = static_cast<uint32_t>(deck_size) | (static_cast<uint32_t>(info) << 6) | (static_cast<uint32_t>(life) << 10) |
-             (static_cast<uint32_t>(cur) << 13) | (static_cast<uint32_t>(turns & 7) << 16) |
-             (static_cast<uint32_t>(moves & 255) << 21);
+        w0 = static_cast<uint32_t>(deck2) | (static_cast<uint32_t>(info2) << 6) | (static_cast<uint32_t>(life2) << 10) |
+             (static_cast<uint32_t>(cur) << 13) | (static_cast<uint32_t>(turns2 & 7) << 16) |
+             (static_cast<uint32_t>((moves + 1) & 255) << 21);
         const int after = score_now();
         int status = 0;
-        if (life < 1) status = 1;
+        if (life2 < 1) status = 1;
         else if (after >= C * R) status = 2;
-        else if (turns <= 0) status = 3;
+        else if (turns2 <= 0) status = 3;
         w0 |= static_cast<uint32_t>(status) << 19;
         int r = after - before;
         if ((a.flags & 4) && r < 0) r = 0;
@@ -424,11 +413,10 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
         out_term = status != 0;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          if (((w3 >> q) & 1u) && !((w3 >> (5 + q)) & 1u)) {
-            const int8_t v = static_cast<int8_t>(static_cast<int8_t>(accw >> (8 * q)) + r);
-            accw = (accw & ~(0xFFull << (8 * q))) | (static_cast<uint64_t>(static_cast<uint8_t>(v)) << (8 * q));
-            if (out_term) w3 |= 1u << (5 + q);
-          }
+          const bool live = ((w3 >> q) & 1u) && !((w3 >> (5 + q)) & 1u);
+          const int8_t v = static_cast<int8_t>(static_cast<int8_t>(accw >> (8 * q)) + (live ? r : 0));
+          accw = (accw & ~(0xFFull << (8 * q))) | (static_cast<uint64_t>(static_cast<uint8_t>(v)) << (8 * q));
+          if (live && out_term) w3 |= 1u << (5 + q);
         }
         if (out_term && (a.flags & 1)) {
           need_reset = true;
