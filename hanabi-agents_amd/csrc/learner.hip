@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   const float zi = atom ? support[lane] : 0.f;
   const float tz = fminf(fmaxf(rew[b] + gamma * zi, vmin), vmax);  // clipped r + gamma * z_j held by lane j
   float target = 0.f;
-  for (int j = 0; j < K; ++j) {
-    const float pj = __shfl(p, j), tzj = __shfl(tz, j);
-    target += pj * fminf(fmaxf(1.f - fabsf(tzj - zi) / delta, 0.f), 1.f);
+  const float inv_delta = 1.f / delta;
+  for (int j = 0; j < K; ++j) {  // j is wave-uniform: the broadcasts are v_readlane, not LDS permutes
+    const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
+    const float tzj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz), j));
+    target += pj * fminf(fmaxf(1.f - fabsf(tzj - zi) * inv_delta, 0.f), 1.f);
   }
   if (!atom) target = 0.f;
   // ---- cross-entropy against log_softmax(online(obs_tm1)[a_tm1]) and its gradient
@@ -240,6 +242,39 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
     m = a.m_sg[i]; v = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], g * nz, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
+    st<T>(eff, (i / a.cols) * a.eff_ld + (i % a.cols), w + mu + sg * nz);
+  }
+}
+
+// all merged tensors of the network in ONE launch: workgroup b belongs to tensor t where first[t] <= b < first[t+1]
+struct AdamMulti {
+  AdamArgs t[8];
+  int first[9];
+  int count;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m) {
+  int ti = 0;
+  while (ti + 1 < m.count && static_cast<int>(blockIdx.x) >= m.first[ti + 1]) ++ti;
+  const AdamArgs& a = m.t[ti];
+  const int nb = m.first[ti + 1] - m.first[ti];
+  const float t = *a.step + 1.f;
+  const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
+  T* eff = static_cast<T*>(a.eff);
+  for (long long i = static_cast<long long>(blockIdx.x - m.first[ti]) * 256 + threadIdx.x; i < a.n;
+       i += static_cast<long long>(nb) * 256) {
+    const float g = a.grad[i], nz = a.noise[i];
+    float mm, vv;
+    mm = a.m_w[i]; vv = a.v_w[i];
+    const float w = adam1(a.w[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_w[i] = mm; a.v_w[i] = vv; a.w[i] = w;
+    mm = a.m_mu[i]; vv = a.v_mu[i];
+    const float mu = adam1(a.w_mu[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_mu[i] = mm; a.v_mu[i] = vv; a.w_mu[i] = mu;
+    mm = a.m_sg[i]; vv = a.v_sg[i];
+    const float sg = adam1(a.w_sigma[i], g * nz, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    a.m_sg[i] = mm; a.v_sg[i] = vv; a.w_sigma[i] = sg;
     st<T>(eff, (i / a.cols) * a.eff_ld + (i % a.cols), w + mu + sg * nz);
   }
 }
@@ -340,6 +375,36 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
   if (eff_dtype == 0) launch_adam<float>(a, s);
   else if (eff_dtype == 1) launch_adam<__hip_bfloat16>(a, s);
   else if (eff_dtype == 2) launch_adam<__half>(a, s);
+  else return fail(HB_ERR_INVALID, "eff_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const float* step_dev, int32_t eff_dtype, float lr,
+                        float beta1, float beta2, float eps, void* stream) {
+  if (!tensors || !step_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (count < 1 || count > 8) return fail(HB_ERR_INVALID, "count must be 1..8");
+  AdamMulti m{};
+  m.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const hb_adam_tensor& d = tensors[i];
+    if (!d.w || !d.w_mu || !d.w_sigma || !d.noise || !d.grad || !d.m_w || !d.v_w || !d.m_mu || !d.v_mu || !d.m_sigma ||
+        !d.v_sigma || !d.eff)
+      return fail(HB_ERR_INVALID, "null pointer in tensor %d", i);
+    if (d.n <= 0 || d.cols < 1 || d.eff_ld < d.cols || d.n % d.cols) return fail(HB_ERR_INVALID, "bad shape in tensor %d", i);
+    m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
+                      step_dev, d.eff, d.n, d.cols, d.eff_ld, lr, beta1, beta2, eps};
+    m.first[i] = blocks;
+    long long nb = (d.n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    blocks += static_cast<int>(nb);
+  }
+  m.first[count] = blocks;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
+  else if (eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
+  else if (eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
   else return fail(HB_ERR_INVALID, "eff_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
   return HB_OK;

@@ -193,7 +193,10 @@ struct InsertArgs {
   int L, A;
 };
 
-// segment s (0 or 1) of the wrapped range: rows [row0, row0+rows) -> slots [slot0, slot0+rows)
+// One pass over the batch: every 16-byte chunk of last_obs / obs is read once and written to its three
+// destinations by the same thread (ring.obs_tm1 <- last_obs, ring.obs_t <- obs, last_obs <- obs), so the
+// read-before-overwrite of last_obs needs no second launch. The ring range may wrap: segment 0 = rows before the
+// wrap, segment 1 = the rest.
 __global__ __launch_bounds__(256) void replay_insert_kernel(const InsertArgs a) {
   const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -203,27 +206,30 @@ __global__ __launch_bounds__(256) void replay_insert_kernel(const InsertArgs a) 
     const long long rows = seg == 0 ? first : a.n - first;
     const long long slot0 = seg == 0 ? a.start : 0;
     if (rows <= 0) continue;
-    // old last_obs -> ring.obs_tm1 ; new obs -> ring.obs_t and last_obs ; legal -> ring.lms
-    copy2(a.last_obs + row0 * a.L, a.ring_obs_tm1 + slot0 * a.L, nullptr, rows * a.L, tid, nthreads);
+    const long long bytes = rows * a.L, vec = bytes >> 4;
+    int8_t* lo = a.last_obs + row0 * a.L;
+    const int8_t* ob = a.obs + row0 * a.L;
+    int8_t* r1 = a.ring_obs_tm1 + slot0 * a.L;
+    int8_t* r2 = a.ring_obs_t + slot0 * a.L;
+    for (long long i = tid; i < vec; i += nthreads) {
+      const u32x4 old = *reinterpret_cast<const u32x4_u*>(lo + (i << 4));
+      const u32x4 cur = *reinterpret_cast<const u32x4_u*>(ob + (i << 4));
+      *reinterpret_cast<u32x4_u*>(r1 + (i << 4)) = old;
+      *reinterpret_cast<u32x4_u*>(r2 + (i << 4)) = cur;
+      *reinterpret_cast<u32x4_u*>(lo + (i << 4)) = cur;
+    }
+    for (long long b = (vec << 4) + tid; b < bytes; b += nthreads) {
+      const int8_t old = lo[b], cur = ob[b];
+      r1[b] = old;
+      r2[b] = cur;
+      lo[b] = cur;
+    }
     copy2(a.legal + row0 * a.A, a.ring_lms + slot0 * a.A, nullptr, rows * a.A, tid, nthreads);
     for (long long i = tid; i < rows; i += nthreads) {
       a.ring_act[slot0 + i] = static_cast<int8_t>(a.actions[row0 + i]);
       a.ring_rew[slot0 + i] = a.rewards[row0 + i];
       a.ring_term[slot0 + i] = a.step_type[row0 + i] == 2;
     }
-  }
-}
-// second launch (after the first has consumed last_obs): obs -> ring.obs_t and last_obs
-__global__ __launch_bounds__(256) void replay_insert_obs_kernel(const InsertArgs a) {
-  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const long long nthreads = static_cast<long long>(gridDim.x) * blockDim.x;
-  const long long first = a.cap - a.start < a.n ? a.cap - a.start : a.n;
-  for (int seg = 0; seg < 2; ++seg) {
-    const long long row0 = seg == 0 ? 0 : first;
-    const long long rows = seg == 0 ? first : a.n - first;
-    const long long slot0 = seg == 0 ? a.start : 0;
-    if (rows <= 0) continue;
-    copy2(a.obs + row0 * a.L, a.ring_obs_t + slot0 * a.L, a.last_obs + row0 * a.L, rows * a.L, tid, nthreads);
   }
 }
 
@@ -317,7 +323,6 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(replay_insert_kernel, dim3(blocks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(replay_insert_obs_kernel, dim3(blocks), dim3(256), 0, s, a);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

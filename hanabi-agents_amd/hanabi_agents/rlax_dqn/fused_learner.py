@@ -79,6 +79,7 @@ class FusedLearner:
         self.AK = AK
         self.support = agent.atoms[0].contiguous()
         self._gb2_pad = torch.zeros(self.Np, **f32)
+        self._adam_tab = None
         self.refresh_effective()
         self.refresh_target()
 
@@ -129,21 +130,32 @@ class FusedLearner:
         K.check(L.hb_colsum(K.dptr(dh), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         return self.td, self.w_is
 
+    def _adam_table(self):
+        """ctypes array describing the four merged tensors (built once: all pointers are persistent)."""
+        if self._adam_tab is None:
+            grads = ((self.g_w1, self.g_b1), (self.g_w2, self.g_b2))
+            tab = (K.HbAdamTensor * 4)()
+            k = 0
+            for li, l in enumerate(self.layers):
+                for names, noise, g, eff in ((("w", "w_mu", "w_sigma"), l.eps_w, grads[li][0], self.eff[li][0]),
+                                             (("b", "b_mu", "b_sigma"), l.eps_b, grads[li][1], self.eff[li][1])):
+                    ps = [getattr(l, n) for n in names]
+                    st = [self.state[(li, n)] for n in names]
+                    d = tab[k]
+                    d.w, d.w_mu, d.w_sigma = (p.data_ptr() for p in ps)
+                    d.noise, d.grad = noise.data_ptr(), g.data_ptr()
+                    d.m_w, d.v_w = st[0][0].data_ptr(), st[0][1].data_ptr()
+                    d.m_mu, d.v_mu = st[1][0].data_ptr(), st[1][1].data_ptr()
+                    d.m_sigma, d.v_sigma = st[2][0].data_ptr(), st[2][1].data_ptr()
+                    d.eff, d.n, d.cols, d.eff_ld = eff.data_ptr(), ps[0].numel(), ps[0].shape[-1], eff.shape[-1]
+                    k += 1
+            self._adam_tab = tab
+        return self._adam_tab
+
     def part2(self):
-        a, L = self.agent, K.lib()
-        p = a.params
-        s = K.current_stream()
-        grads = ((self.g_w1, self.g_b1), (self.g_w2, self.g_b2))
-        for li, l in enumerate(self.layers):
-            for names, noise, g, eff in ((("w", "w_mu", "w_sigma"), l.eps_w, grads[li][0], self.eff[li][0]),
-                                         (("b", "b_mu", "b_sigma"), l.eps_b, grads[li][1], self.eff[li][1])):
-                ps = [getattr(l, n) for n in names]
-                st = [self.state[(li, n)] for n in names]
-                K.check(L.hb_noisy_adam(K.dptr(ps[0]), K.dptr(ps[1]), K.dptr(ps[2]), K.dptr(noise), K.dptr(g),
-                                        K.dptr(st[0][0]), K.dptr(st[0][1]), K.dptr(st[1][0]), K.dptr(st[1][1]),
-                                        K.dptr(st[2][0]), K.dptr(st[2][1]), K.dptr(self.step), K.dptr(eff), _DT[self.cd],
-                                        ps[0].numel(), ps[0].shape[-1], eff.shape[-1], float(p.learning_rate), 0.9,
-                                        0.999, 3.125e-5, s))
+        p = self.agent.params
+        K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), _DT[self.cd], float(p.learning_rate),
+                                            0.9, 0.999, 3.125e-5, K.current_stream()))
         self.step.add_(1.0)
 
     def loss(self):

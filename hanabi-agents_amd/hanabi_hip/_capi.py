@@ -36,6 +36,13 @@ def make_config(game="Hanabi-Full", players=2, flags=0):
     return HbConfig(players, g["colors"], g["ranks"], g["hand_size"](players), g["max_info"], g["max_life"], flags)
 
 
+class HbAdamTensor(C.Structure):
+    """`hb_adam_tensor` of include/hanabi_hip.h."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("w", "w_mu", "w_sigma", "noise", "grad", "m_w", "v_w", "m_mu", "v_mu", "m_sigma",
+                                          "v_sigma", "eff")] + [("n", C.c_int64), ("cols", C.c_int32), ("eff_ld", C.c_int32)]
+
+
 def library_path():
     # HANABI_HIP_LIB lets scripts/env_stamps.py load the diagnostic (-DHB_STAMPS) build of the same ABI
     return os.environ.get("HANABI_HIP_LIB") or os.path.join(_HERE, "libhanabi_hip.so")
@@ -86,6 +93,7 @@ SIGNATURES = {
     "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "hb_noisy_adam": (C.c_int, [_P] * 11 + [_P, _P, _I32, _I64, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "hb_noisy_adam_multi": (C.c_int, [C.POINTER(HbAdamTensor), _I32, _P, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }
 

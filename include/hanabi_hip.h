@@ -284,6 +284,20 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
                   const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, int32_t cols, int32_t eff_ld, float lr,
                   float beta1, float beta2, float eps, void* stream);
 
+/* The same for up to 8 merged tensors (all layers' weights and biases) in ONE launch.        */
+typedef struct hb_adam_tensor {
+  float *w, *w_mu, *w_sigma;
+  const float* noise;
+  const float* grad;
+  float *m_w, *v_w, *m_mu, *v_mu, *m_sigma, *v_sigma;
+  void* eff;
+  int64_t n;
+  int32_t cols, eff_ld;
+} hb_adam_tensor;
+int hb_noisy_adam_multi(const hb_adam_tensor* tensors /* host array of device pointers */, int32_t count,
+                        const float* step_dev, int32_t eff_dtype, float lr, float beta1, float beta2, float eps,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
