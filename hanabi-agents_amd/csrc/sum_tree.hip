@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ n
 }
 
 __global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict__ nodes, long long cap, int depth,
-                                                         const double* __restrict__ u, long long batch,
+                                                         const double* __restrict__ u, long long batch, int unit,
                                                          int64_t* __restrict__ idx, double* __restrict__ prob) {
   const int lane = threadIdx.x & 63;
   const long long i = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict
   const double step = batch > 1 ? (1.0 - start) / static_cast<double>(batch - 1) : 0.0;
   const double lin = (batch > 1 && i == batch - 1) ? 1.0 : static_cast<double>(i) * step + start;
   const float total = nodes[1];
-  const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(static_cast<float>(lin - u[i]) * total)));
+  const double ui = unit ? u[i] / static_cast<double>(batch) : u[i];  // unit: u in [0,1) is scaled to the stratum width here
+  const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(static_cast<float>(lin - ui) * total)));
   float leaf;
   const long long k = wave_descend(nodes, cap, depth, query, lane, &leaf);
   if (lane == 0) {
@@ -411,13 +412,14 @@ int hb_tree_sample(hb_tree* t, const float* quantile_dev, int64_t* idx_dev, floa
   return HB_OK;
 }
 
-int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int64_t* idx_dev, double* prob_dev, void* stream) {
+int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_uniforms, int64_t* idx_dev, double* prob_dev,
+                  void* stream) {
   if (!t) return fail(HB_ERR_INVALID, "null tree");
   if (batch <= 0) return HB_OK;
   if (!u_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
   hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, u_dev, static_cast<long long>(batch),
-                     idx_dev, prob_dev);
+                     unit_uniforms != 0 ? 1 : 0, idx_dev, prob_dev);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

@@ -170,7 +170,7 @@ class DQNAgent:
         self.last_obs = torch.zeros((n_games, obs_len), dtype=torch.int8, device=self.device)
         self.requires_vectorized_observation = lambda: True
         self._gen = torch.Generator(device=self.device).manual_seed(params.seed + 1)
-        self.last_loss = None
+        self._last_loss = None
         # fused HIP actor tail / replay insert (hanabi_hip.ops) on the GPU; plain torch ops elsewhere
         self._fused = self.device.type == "cuda" and self.distributional
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
@@ -182,6 +182,17 @@ class DQNAgent:
         self.use_fused_learner = use_fused_learner
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
+
+    @property
+    def last_loss(self):
+        """mean(td * w_IS) of the most recent update (rlax_rainbow.py:196)."""
+        if self._fl is not None and self._last_loss is None:
+            return self._fl.loss()
+        return self._last_loss
+
+    @last_loss.setter
+    def last_loss(self, value):
+        self._last_loss = value
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _unpack(self, observations) -> Tuple[torch.Tensor, torch.Tensor, bool]:
@@ -432,8 +443,8 @@ class DQNAgent:
     def _sample_indices(self):
         b = self.params.train_batch_size
         if self.params.use_priority:
-            u = torch.rand(b, dtype=torch.float64, device=self.device) / b
-            return self.experience.sum_tree.per_sample_dev(u)
+            u = torch.rand(b, dtype=torch.float64, device=self.device)  # scaled to [0, 1/B) inside the kernel
+            return self.experience.sum_tree.per_sample_dev(u, unit=True)
         return self.experience.sample_indices_dev(b), torch.ones(b, dtype=torch.float64, device=self.device)
 
     def _update_part1(self):
@@ -446,7 +457,7 @@ class DQNAgent:
                 fl.refresh_target()
             indices, prios = self._sample_indices()
             td, _ = fl.part1(indices, prios)
-            return fl.loss(), indices, td
+            return None, indices, td  # the loss value is formed on demand (last_loss) from td and the IS weights
         indices, prios, tr = self._sample()
         if self.params.resample_noise:
             self.online.resample()

@@ -85,7 +85,7 @@ SIGNATURES = {
     "hb_tree_get": (C.c_int, [_P, _P, _P, _I64, _P]),
     "hb_tree_total": (C.c_int, [_P, _P, _P]),
     "hb_tree_error_count": (C.c_int, [_P, C.POINTER(_I64)]),
-    "hb_per_sample": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "hb_per_sample": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "hb_per_update": (C.c_int, [_P, _P, _P, _I64, _F64, _P, _P, _P]),
     "hb_obs_cast": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "hb_policy_act": (C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _I32, C.c_float, _U64, _U64, _I64, _P, _P, _P]),

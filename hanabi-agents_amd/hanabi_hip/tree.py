@@ -59,13 +59,14 @@ class SumTree:
         K.check(self.L.hb_tree_total(self.h, K.dptr(self._total), K.current_stream()))
         return self._total
 
-    def per_sample_dev(self, u, idx_out=None, prob_out=None):
-        """Stratified PER sampling on given uniforms u[i] in [0, 1/B) (float64) -> (indices, probabilities)."""
+    def per_sample_dev(self, u, idx_out=None, prob_out=None, unit=False):
+        """Stratified PER sampling on given uniforms u[i] in [0, 1/B) — or in [0, 1) with unit=True — (float64)
+        -> (indices, probabilities)."""
         assert u.dtype == torch.float64 and u.is_cuda
         b = u.numel()
         idx = idx_out if idx_out is not None else torch.empty(b, dtype=torch.int64, device=self.device)
         prob = prob_out if prob_out is not None else torch.empty(b, dtype=torch.float64, device=self.device)
-        K.check(self.L.hb_per_sample(self.h, K.dptr(u), b, K.dptr(idx), K.dptr(prob), K.current_stream()))
+        K.check(self.L.hb_per_sample(self.h, K.dptr(u), b, 1 if unit else 0, K.dptr(idx), K.dptr(prob), K.current_stream()))
         return idx, prob
 
     def per_update_dev(self, idx, td, alpha, max_prio_dev, min_prio_dev):

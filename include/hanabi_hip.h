@@ -203,9 +203,10 @@ int hb_tree_error_count(hb_tree* t, int64_t* out); /* synchronises the stream */
 /* ---- fused prioritized-replay helpers (priority_buffer.py:36-52) ----------------------
  * hb_per_sample: keys_i = float(linspace(1/B, 1, B)_i - u_i) with u_i in [0, 1/B) given
  * as doubles (priority_buffer.py:37-40), tree descent, and
- * prob_i = (leaf_i + 1e-10) / total in double (priority_buffer.py:42).                  */
-int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int64_t* idx_dev, double* prob_dev,
-                  void* stream);
+ * prob_i = (leaf_i + 1e-10) / total in double (priority_buffer.py:42). unit_uniforms != 0:
+ * u_i is in [0, 1) and is divided by B inside the kernel (saves the caller a launch).    */
+int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_uniforms, int64_t* idx_dev,
+                  double* prob_dev, void* stream);
 /* hb_per_update: p_i = (|td_i| + 1e-10)^alpha (double pow, rounded to float as the
  * pybind float conversion does), max/min priority tracked in device scalars
  * (priority_buffer.py:48-52), then hb_tree_update.                                      */
