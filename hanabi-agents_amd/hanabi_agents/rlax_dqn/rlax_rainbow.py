@@ -501,9 +501,11 @@ class DQNAgent:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph1):
+        # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog polling its events in a
+        # data-parallel run) must not invalidate the capture
+        with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
             self.last_loss, self._g_idx, self._g_prios = self._update_part1()
-        with torch.cuda.graph(self._graph2, pool=self._graph1.pool()):
+        with torch.cuda.graph(self._graph2, pool=self._graph1.pool(), capture_error_mode="thread_local"):
             self._update_part2(self._g_idx, self._g_prios)
 
     def _dp_world(self):
