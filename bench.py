@@ -98,6 +98,64 @@ def cpu_baseline(args):
                       f"(oracle/hanabi_oracle.c: step + legal mask + canonical encoder, random-legal policy)"}
 
 
+def sum_tree_baseline(device):
+    """The one hot-path piece of the reference that builds here: its C++ SumTree<float> (oracle/_ref, compiled from
+    sum_tree/sum_tree/include/sum_tree.h by oracle/Makefile) timed on the host, next to the HIP tree on the GPU,
+    for the three operations of the PER cycle at capacity 2^19 (priority_buffer.py:29-52)."""
+    import numpy as np
+
+    from oracle import oracle_py as O
+    import hanabi_hip
+
+    out = {"kind": "reference", "capacity": 2 ** 19, "unit": "us per call"}
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, 300000, 256)
+    val = rng.random(256).astype(np.float32)
+    q = rng.random(256).astype(np.float32)
+    if O.RefTree.available():
+        import ctypes
+
+        # one OpenMP thread is the reference's fastest setting (BASELINE.md §2: its per-node mutexes make more threads
+        # slower; with the box's default of one thread per visible core it is ~40x slower still)
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        out["reference_threads"] = 1
+        ref = O.RefTree(2 ** 19)
+        ins = np.arange(32768)
+        t0 = time.perf_counter(); ref.update(ins, np.full(32768, 0.6, np.float32)); ins_s = time.perf_counter() - t0
+        ref.update(np.arange(32768, 300000), np.full(300000 - 32768, 0.6, np.float32))
+
+        def tm(fn, reps=200):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e6
+
+        out["reference_cpu"] = {"update_values_256": tm(lambda: ref.update(idx, val)), "get_indices_256": tm(lambda: ref.sample(q)),
+                                "insert_32768": ins_s * 1e6}
+    tree = hanabi_hip.SumTree(2 ** 19, device=device)
+    mx = torch.tensor([0.6], device=device)
+    mn = mx.clone()
+    tree.fill_range_dev(0, 300000, mx)
+    di, dv = torch.as_tensor(idx, device=device), torch.as_tensor(val, device=device)
+    du = torch.as_tensor(rng.random(256), device=device)
+
+    def tg(fn, reps=200):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+
+    out["hip_gpu"] = {"update_values_256": tg(lambda: tree.per_update_dev(di, dv, 0.6, mx, mn)),
+                      "get_indices_256": tg(lambda: tree.per_sample_dev(du, unit=True)),
+                      "insert_32768": tg(lambda: tree.fill_range_dev(1000, 32768, mx))}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,6 +293,7 @@ def main():
         line["roofline_qnet"] = qnet_roofline(agents[0], env, args)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args)
+        line["cpu_baseline_sum_tree"] = sum_tree_baseline(device)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
