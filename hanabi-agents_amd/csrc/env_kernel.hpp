@@ -190,16 +190,20 @@ __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride
   constexpr int CPR = L / 16, TAIL = L % 16;
   if constexpr (CPR > 0) {
     const int chunks = nvalid * CPR;
-    // four chunks per lane per trip: the four LDS reads are issued back to back, then four stores
+    // lane -> chunks lane, lane+64, ...: (row g, chunk l) advance incrementally (no division per chunk): +64
+    // chunks = +Q rows and +Rm chunks with one carry
+    constexpr int Q = 64 / CPR, Rm = 64 % CPR;
+    int g = lane / CPR, l = lane - g * CPR;
     for (int c0 = lane; c0 < chunks; c0 += 256) {
       uint32_t v[4];
       int off[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 64 * u;
-        const int g = c / CPR, l = c - g * CPR;
         off[u] = g * L + 16 * l;
-        v[u] = c < chunks ? reinterpret_cast<const uint16_t*>(bits + g * row_stride)[l] : 0u;
+        v[u] = (c0 + 64 * u) < chunks ? reinterpret_cast<const uint16_t*>(bits + g * row_stride)[l] : 0u;
+        g += Q;
+        l += Rm;
+        if (l >= CPR) { l -= CPR; ++g; }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
