@@ -129,6 +129,30 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// Colour-plausibility bits c -> bit c*R. Bit c has to move up by (R-1)*c: multiply by sum_k 2^((R-1)k) and keep,
+// of copy k, only bit k. The even and the odd colours go separately so that neighbouring copies (2(R-1) apart)
+// never overlap and no addition carries.
+template <int C, int R>
+__device__ __forceinline__ uint32_t spread_colors(uint32_t cp) {
+  if constexpr (2 * (R - 1) >= C && C * R <= 24 + 1) {
+    constexpr auto sum = [](int first, int step) constexpr {
+      uint32_t v = 0;
+      for (int k = first; k < C; k += 2) v |= 1u << (step * k);
+      return v;
+    };
+    constexpr uint32_t EIN = sum(0, 1), OIN = sum(1, 1), EMUL = sum(0, R - 1), OMUL = sum(1, R - 1), ESEL = sum(0, R),
+                       OSEL = sum(1, R);
+    uint32_t v = __umul24(cp & EIN, EMUL) & ESEL;
+    if constexpr (C > 1) v |= __umul24(cp & OIN, OMUL) & OSEL;
+    return v;
+  } else {
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) v |= ((cp >> c) & 1u) << (c * R);
+    return v;
+  }
+}
+
 // bit-packed observation under construction; every offset is a compile-time constant so the
 // words stay in VGPRs
 template <int NW>
@@ -390,7 +414,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
         const int n_s_after = card_move ? (draws ? n_s : n_s - 1) : n_s;
         w1 = (w1 & ~(7u << (15 + 3 * s))) | (static_cast<uint32_t>(n_s_after) << (15 + 3 * s));
         if (success) w1 += 1u << (3 * c_col);
-        if (to_discard) disc += 1ull << (2 * card);
+        {  // discard pile = the observation's discard section itself (one thermometer per card identity): the
+           // next bit of this card's field is (field << 1 | 1), clipped to the field's width
+          const int dpos = (c_col * K::CPC + (c_rank ? 2 * c_rank + 1 : 0)) & 63;  // cum(rank) = 2*rank + 1 past rank 0
+          const uint32_t dmask = c_rank == 0 ? 7u : (c_rank == R - 1 ? 1u : 3u);
+          const uint32_t dfield = static_cast<uint32_t>(disc >> dpos) & dmask;
+          const uint32_t dnew = to_discard ? (((dfield << 1) | 1u) & dmask) : 0u;
+          disc |= static_cast<uint64_t>(dnew) << dpos;
+        }
         const int info2 = info + (card_move ? la_info : -1);
         const int life2 = life - (fail ? 1 : 0);
         const int deck2 = deck_size - ((card_move && draws) ? 1 : 0);
@@ -521,13 +552,8 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       });
       acc.template put<K::INFO_OFF, K::INFO>((1u << info) - 1u);
       acc.template put<K::LIFE_OFF, K::LIFE>((1u << life) - 1u);
-      // 3. discards: one thermometer per card identity
-      static_for<C * R>([&](auto CR) {
-        constexpr int cr = decltype(CR)::value;
-        constexpr int c = cr / R, r = cr % R;
-        const uint32_t cnt = static_cast<uint32_t>(disc >> (2 * cr)) & 3u;
-        acc.template put<K::DISC_OFF + c * K::CPC + K::cum(r), K::copies(r)>((1u << cnt) - 1u);
-      });
+      // 3. discards: one thermometer per card identity,
+      acc.template put64<K::DISC_OFF, K::D>(disc);  // kept in this very form in the state row
       // 4. most recent move, observer-relative
       {
         const uint32_t valid = w2 & 1u;
@@ -566,10 +592,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
           constexpr int i = decltype(I)::value;
           const uint32_t k = static_cast<uint32_t>(kn >> (12 * i)) & 0xFFFu;
           const uint32_t cp = k & 31u, rp = (k >> 5) & 31u;
-          uint32_t spread = 0;  // colour c plausible -> bit c*R
-#pragma unroll
-          for (int c = 0; c < C; ++c) spread |= ((cp >> c) & 1u) << (c * R);
-          const uint32_t plaus = spread * rp;  // disjoint R-bit fields: no carries
+          const uint32_t plaus = __umul24(spread_colors<C, R>(cp), rp);  // disjoint R-bit fields: no carries
           const uint32_t ch = (k >> 10) & 1u, rh = (k >> 11) & 1u;
           uint64_t v = plaus | (static_cast<uint64_t>(ch ? cp : 0u) << K::BITS) |
                        (static_cast<uint64_t>(rh ? rp : 0u) << (K::BITS + C));

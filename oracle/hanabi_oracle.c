@@ -552,10 +552,14 @@ void orc_env_export_state(const orc_env* e, uint32_t* rows) {
       w[4 + p / 4] |= (uint32_t)(uint8_t)(int8_t)g->acc[p] << (8 * (p % 4));
     }
     w[6] = g->episode;
-    for (int i = 0; i < c->colors * c->ranks; ++i) {
-      uint64_t v = (uint64_t)g->discard_count[i] << (2 * i);
-      w[8] |= (uint32_t)v;
-      w[9] |= (uint32_t)(v >> 32);
+    { /* discard pile in the form the encoder emits it: one thermometer per card identity */
+      int pos = 0;
+      for (int i = 0; i < c->colors * c->ranks; ++i) {
+        uint64_t v = (((uint64_t)1 << g->discard_count[i]) - 1) << pos;
+        w[8] |= (uint32_t)v;
+        w[9] |= (uint32_t)(v >> 32);
+        pos += copies_of_rank(c, i % c->ranks);
+      }
     }
     for (int p = 0; p < P; ++p) {
       uint32_t cards = 0;

@@ -136,8 +136,13 @@ def test_full_size_properties_32768_games():
             dsz = st[:, 0] & 63
             cnt = np.zeros((n, 25), np.int64)
             d64 = st[:, 8].astype(np.uint64) | (st[:, 9].astype(np.uint64) << np.uint64(32))
+            pos = 0                                                             # words 8-9: thermometer per card identity
             for i in range(25):
-                cnt[:, i] += ((d64 >> np.uint64(2 * i)) & np.uint64(3)).astype(np.int64)
+                for k in range(int(copies[i])):
+                    cnt[:, i] += ((d64 >> np.uint64(pos + k)) & np.uint64(1)).astype(np.int64)
+                pos += int(copies[i])
+            assert np.array_equal(np.unpackbits(d64.view(np.uint8).reshape(n, 8), axis=1, bitorder="little")[:, :50],
+                                  obs[:, 203:253].astype(np.uint8))             # and it IS the observation's discard section
             for c in range(5):
                 f = (st[:, 1] >> (3 * c)) & 7
                 for r in range(5):

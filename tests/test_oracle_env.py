@@ -158,7 +158,12 @@ def _unpack(cfg, row):
     d["fireworks"] = [(row[1] >> (3 * c)) & 7 for c in range(cfg.colors)]
     d["hand_n"] = [(row[1] >> (15 + 3 * p)) & 7 for p in range(P)]
     disc = int(row[8]) | int(row[9]) << 32
-    d["discards"] = [(disc >> (2 * i)) & 3 for i in range(cfg.colors * cfg.ranks)]
+    copies = [3 if r == 0 else (1 if r == cfg.ranks - 1 else 2) for r in range(cfg.ranks)]
+    d["discards"], pos = [], 0                # words 8-9: the encoder's discard section (thermometer per card identity)
+    for i in range(cfg.colors * cfg.ranks):
+        n = copies[i % cfg.ranks]
+        d["discards"].append(bin((disc >> pos) & ((1 << n) - 1)).count("1"))
+        pos += n
     d["hands"] = [[(int(row[10 + p]) >> (5 * i)) & 31 for i in range(d["hand_n"][p])] for p in range(P)]
     return d
 
