@@ -448,6 +448,13 @@ int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream) {
   return HB_OK;
 }
 
+int hb_tree_import_nodes(hb_tree* t, const float* nodes_dev, void* stream) {
+  if (!t || !nodes_dev) return fail(HB_ERR_INVALID, "null argument");
+  HB_HIP(hipMemcpyAsync(t->nodes, nodes_dev, 2 * t->cap * sizeof(float), hipMemcpyDeviceToDevice,
+                        static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+
 int hb_tree_error_count(hb_tree* t, int64_t* out) {
   if (!t || !out) return fail(HB_ERR_INVALID, "null argument");
   unsigned long long v = 0;

@@ -95,6 +95,32 @@ class ExperienceBuffer:
             for buf, val in cols:
                 buf[dst] = val[src]
 
+    # ---- checkpointing (the reference saves network parameters only) ---------------------
+    _DATA = ("_obs_tm1_buf", "_act_tm1_buf", "_obs_t_buf", "_lms_t_buf", "_rew_t_buf", "_terminal_t_buf")
+
+    def state_dict(self, include_data=True):
+        """Ring pointers, sampler RNG and (optionally) the `size` rows written so far, as host tensors."""
+        sd = dict(capacity=self.capacity, oldest_entry=self.oldest_entry, size=self.size,
+                  rows_per_insert=self.rows_per_insert, gen=self._gen.get_state().cpu(), has_data=bool(include_data))
+        if include_data:
+            sd["data"] = {name: getattr(self, name)[:self.size].cpu() for name in self._DATA}
+        return sd
+
+    def load_state_dict(self, sd):
+        """In place (captured graphs keep pointing at the same buffers)."""
+        if sd["capacity"] != self.capacity:
+            raise ValueError(f"checkpoint ring capacity {sd['capacity']} != {self.capacity}")
+        if sd["has_data"]:
+            for name in self._DATA:
+                rows = sd["data"][name]
+                getattr(self, name)[:rows.shape[0]].copy_(rows)
+            self.oldest_entry, self.size = int(sd["oldest_entry"]), int(sd["size"])
+        else:  # weights-only resume: start with an empty ring
+            self.oldest_entry, self.size = 0, 0
+        self.rows_per_insert = sd["rows_per_insert"] if sd["has_data"] else None
+        self._gen.set_state(sd["gen"].cpu())
+        self.sync_size()
+
     # ---- access ---------------------------------------------------------------------------------
     def gather_dev(self, indices: torch.Tensor) -> Transition:
         """Batch as device tensors (the learner's path)."""

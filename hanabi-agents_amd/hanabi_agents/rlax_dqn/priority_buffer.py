@@ -43,6 +43,24 @@ class PriorityBuffer(ExperienceBuffer):
             self.sum_tree.fill_range_dev(self.oldest_entry, batch_size, self._max_priority)
         super().add_transitions(observation_tm1, action_tm1, reward_t, observation_t, legal_moves_t, terminal_t)
 
+    def state_dict(self, include_data=True):
+        sd = super().state_dict(include_data)
+        sd["max_priority"], sd["min_priority"] = self._max_priority.cpu(), self._min_priority.cpu()
+        if include_data:
+            sd["tree_nodes"] = self.sum_tree.nodes().cpu()  # every node: inner sums keep their exact fp32 values
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        if sd["has_data"]:
+            self.sum_tree.import_nodes(sd["tree_nodes"])
+            self._max_priority.copy_(sd["max_priority"])
+            self._min_priority.copy_(sd["min_priority"])
+        else:
+            self.sum_tree.import_nodes(torch.zeros(2 * self.sum_tree.capacity))
+            self._max_priority.fill_(self.alpha)
+            self._min_priority.fill_(self.alpha)
+
     # ---- device path ------------------------------------------------------------------------------
     def sample_batch_dev(self, batch_size, uniforms=None):
         """(indices int64 [B], probabilities float64 [B], Transition of device tensors).

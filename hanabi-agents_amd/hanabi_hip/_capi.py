@@ -79,6 +79,7 @@ SIGNATURES = {
     "hb_tree_capacity": (_I64, [_P]),
     "hb_tree_nodes": (_P, [_P]),
     "hb_tree_export_nodes": (C.c_int, [_P, _P, _P]),
+    "hb_tree_import_nodes": (C.c_int, [_P, _P, _P]),
     "hb_tree_update": (C.c_int, [_P, _P, _P, _I64, _P]),
     "hb_tree_fill_range": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "hb_tree_sample": (C.c_int, [_P, _P, _P, _P, _I64, _P]),

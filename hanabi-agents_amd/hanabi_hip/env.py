@@ -32,6 +32,7 @@ class HanabiEnv:
         self.deck_size = self.L.hb_deck_size(C.byref(self.cfg))
         self.state_words = self.L.hb_state_words(C.byref(self.cfg))
         self.first_game_id = int(first_game_id)
+        self.seed = int(seed)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             K.check(self.L.hb_env_create(C.byref(self.cfg), self.n, seed, first_game_id, C.byref(h)))

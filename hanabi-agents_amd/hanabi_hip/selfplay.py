@@ -120,6 +120,53 @@ class SelfPlaySession:
             self.step(train=train)
         self.flush()
 
+    # ---- checkpoint / resume -----------------------------------------------------------------
+    def checkpoint_state(self, include_replay=True):
+        """Everything a bit-exact resume needs: env rows (the deck pool is re-derived from them), turn counter,
+        pending actions, progress counters and one checkpoint per distinct agent."""
+        self.flush()
+        torch.cuda.synchronize(self.env.device)
+        ep, sc = self.env.stats()
+        uniq, slot = [], []
+        for a in self.agents:
+            if not any(a is u for u in uniq):
+                uniq.append(a)
+            slot.append(next(i for i, u in enumerate(uniq) if a is u))
+        return dict(format="hanabi-agents_amd/session/1", t=self.t, env_steps=self.env_steps, grad_steps=self.grad_steps,
+                    episodes=ep - self._stats0[0], score_sum=sc - self._stats0[1], games=self.env.n,
+                    env_seed=self.env.seed, first_game_id=self.env.first_game_id,
+                    env_rows=self.env.export_state().cpu(), last_actions=[a.cpu() for a in self.last_actions],
+                    agent_slot=slot, agents=[u.checkpoint_state(include_replay) for u in uniq])
+
+    def load_checkpoint_state(self, sd):
+        if sd.get("format") != "hanabi-agents_amd/session/1":
+            raise ValueError("not a session checkpoint")
+        if sd["games"] != self.env.n or len(sd["agent_slot"]) != len(self.agents):
+            raise ValueError("checkpoint was written for a different number of games / seats")
+        if (sd["env_seed"], sd["first_game_id"]) != (self.env.seed, self.env.first_game_id):
+            raise ValueError("the env's deck seed / first game id differ from the checkpoint's: future deals would diverge")
+        self.flush()
+        self.env.import_state(sd["env_rows"])
+        self.env.observe()  # obs / legal / per-seat reward + step type of the seat about to act
+        for dst, src in zip(self.last_actions, sd["last_actions"]):
+            dst.copy_(src)
+        done = set()
+        for a, k in zip(self.agents, sd["agent_slot"]):
+            if id(a) not in done:
+                a.load_checkpoint_state(sd["agents"][k])
+                done.add(id(a))
+        self.t, self.env_steps, self.grad_steps = int(sd["t"]), int(sd["env_steps"]), int(sd["grad_steps"])
+        ep, sc = self.env.stats()
+        self._stats0 = (ep - sd["episodes"], sc - sd["score_sum"])
+        self._update_done.clear()
+        self._inflight = None
+
+    def save_checkpoint(self, path, include_replay=True):
+        torch.save(self.checkpoint_state(include_replay), path)
+
+    def load_checkpoint(self, path):
+        self.load_checkpoint_state(torch.load(path, map_location="cpu", weights_only=True))
+
     @property
     def episodes(self):
         """Episodes finished since this session started (counted inside the env kernel)."""

@@ -80,6 +80,13 @@ class SumTree:
         K.check(self.L.hb_tree_export_nodes(self.h, K.dptr(out), K.current_stream()))
         return out
 
+    def import_nodes(self, nodes):
+        """Overwrite the heap with a tensor produced by nodes() (checkpoint resume)."""
+        nodes = nodes.to(device=self.device, dtype=torch.float32).contiguous()
+        assert nodes.numel() == 2 * self.capacity
+        K.check(self.L.hb_tree_import_nodes(self.h, K.dptr(nodes), K.current_stream()))
+        torch.cuda.current_stream().synchronize()  # `nodes` may be a temporary
+
     def error_count(self):
         v = C.c_int64()
         K.check(self.L.hb_tree_error_count(self.h, C.byref(v)))

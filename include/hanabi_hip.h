@@ -174,6 +174,9 @@ int64_t hb_tree_capacity(const hb_tree* t);          /* get_capacity() */
 float* hb_tree_nodes(hb_tree* t);
 /* copy of the whole heap into nodes_dev[2*cap] (differential tests) */
 int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream);
+/* the inverse: overwrite the whole heap with nodes_dev[2*cap] as exported above (checkpoint resume: inner
+ * nodes keep the exact fp32 values the incremental updates had produced)                          */
+int hb_tree_import_nodes(hb_tree* t, const float* nodes_dev, void* stream);
 
 /* update_values(indices, values) (sum_tree.h:38-44). Duplicate indices inside one call:
  * the LAST occurrence wins (the sequential order of the reference loop). n<=0 is a no-op.
