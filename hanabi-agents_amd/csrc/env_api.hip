@@ -353,6 +353,8 @@ int hb_env_export_state(hb_env* e, uint32_t* rows_dev, void* stream) {
                         static_cast<hipStream_t>(stream)));
   return HB_OK;
 }
+const uint32_t* hb_env_state(hb_env* e) { return e ? e->state : nullptr; }
+
 int hb_env_import_state(hb_env* e, const uint32_t* rows_dev, void* stream) {
   if (!e || !rows_dev) return fail(HB_ERR_INVALID, "null argument");
   HB_HIP(hipMemcpyAsync(e->state, rows_dev, static_cast<size_t>(e->n) * e->var->state_words * 4, hipMemcpyDeviceToDevice,

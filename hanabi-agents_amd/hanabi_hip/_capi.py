@@ -43,6 +43,19 @@ class HbAdamTensor(C.Structure):
                                           "v_sigma", "eff")] + [("n", C.c_int64), ("cols", C.c_int32), ("eff_ld", C.c_int32)]
 
 
+class HbRule(C.Structure):
+    """`hb_rule` of include/hanabi_hip.h."""
+
+    _fields_ = [("kind", C.c_int32), ("arg", C.c_int32), ("threshold", C.c_float)]
+
+
+(RULE_LEGAL_RANDOM, RULE_DISCARD_OLDEST_FIRST, RULE_OSAWA_DISCARD, RULE_TELL_UNKNOWN, RULE_TELL_RANDOMLY,
+ RULE_PLAY_SAFE_CARD, RULE_PLAY_IF_CERTAIN, RULE_TELL_PLAYABLE_CARD_OUTER, RULE_TELL_DISPENSABLE, RULE_DISCARD_RANDOMLY,
+ RULE_PLAY_PROBABLY_SAFE, RULE_DISCARD_PROBABLY_USELESS, RULE_HAIL_MARY, RULE_TELL_ANYONE_USELESS_CARD,
+ RULE_TELL_PLAYABLE_CARD, RULE_TELL_MOST_INFORMATION) = range(16)
+MAX_RULES = 16
+
+
 def library_path():
     # HANABI_HIP_LIB lets scripts/env_stamps.py load the diagnostic (-DHB_STAMPS) build of the same ABI
     return os.environ.get("HANABI_HIP_LIB") or os.path.join(_HERE, "libhanabi_hip.so")
@@ -70,6 +83,8 @@ SIGNATURES = {
     "hb_env_stats": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "hb_env_export_state": (C.c_int, [_P, _P, _P]),
     "hb_env_import_state": (C.c_int, [_P, _P, _P]),
+    "hb_env_state": (_P, [_P]),
+    "hb_rule_act": (C.c_int, [_CFG, _P, _I64, _I64, C.POINTER(HbRule), _I32, _U64, _U64, _P, _P, _P]),
     "hb_random_legal_actions": (C.c_int, [_P, _I64, _I32, _U64, _U64, _I64, _P, _P]),
     "hb_env_set_games_per_wave": (C.c_int, [_P, _I32]),
     "hb_env_set_async_refill": (C.c_int, [_P, _I32]),

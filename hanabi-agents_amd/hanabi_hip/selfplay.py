@@ -58,7 +58,9 @@ class SelfPlaySession:
         main = torch.cuda.current_stream() if self.learner_stream is not None else None
         if main is not None and id(agent) in self._update_done:
             main.wait_event(self._update_done.pop(id(agent)))  # its replay / weights are being written by that update
-        observations = (None, (env.obs, env.legal))
+        # [0]: the rich observation source for agents with requires_vectorized_observation() False (rule-based
+        # partners read the env's state rows); [1]: the vectorised (obs, legal) pair the DQN agents use
+        observations = (env, (env.obs, env.legal))
         if self.t < env.players:
             # only during the first round can a seat be without a pending move (step type FIRST)
             agent.add_experience_first(observations, env.agent_step_type)
@@ -88,6 +90,8 @@ class SelfPlaySession:
         self.t += 1
 
     def _ready(self, agent):
+        if not hasattr(agent, "experience"):  # passive partner (rule-based): nothing to train
+            return False
         need = self.min_replay if self.min_replay is not None else agent.params.train_batch_size
         return agent.experience.size >= need
 

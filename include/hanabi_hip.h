@@ -145,6 +145,51 @@ int hb_env_import_state(hb_env* env, const uint32_t* rows_dev, void* stream);
 int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_actions, uint64_t seed,
                             uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
 
+/* ---- rule-based partners (hanabi_agents/rule_based/) ------------------------------------
+ * The reference's RulebasedAgent (rule_based.py:13-25) walks a priority list of rules over the rich observation
+ * object of ONE game and takes the first move a rule returns, falling back to a random legal move. Here the same
+ * walk runs for all games in one launch, straight from the env's state rows (a rule only ever reads what the
+ * acting player may see: its own card knowledge, the other hands, fireworks, discards, tokens, deck size).
+ * Rule semantics follow ruleset.py (line numbers at each kind); randomness is Philox(seed; draw, game) instead of
+ * Python's `random` (word 0: card index, word 1: rank-or-colour coin, word 2: discard index, word 3: legal move).
+ * Where ruleset.py hard-codes the full game's 8 information tokens / 5 ranks, the configuration's max_info /
+ * ranks are used.                                                                                   */
+enum {
+  HB_RULE_LEGAL_RANDOM = 0,              /* ruleset.py:598-604                                          */
+  HB_RULE_DISCARD_OLDEST_FIRST = 1,      /* :206-216                                                    */
+  HB_RULE_OSAWA_DISCARD = 2,             /* :220-280                                                    */
+  HB_RULE_TELL_UNKNOWN = 3,              /* :285-308  next player only, colour before rank              */
+  HB_RULE_TELL_RANDOMLY = 4,             /* :314-346  next player only                                  */
+  HB_RULE_PLAY_SAFE_CARD = 5,            /* :350-379  every plausible identity is playable              */
+  HB_RULE_PLAY_IF_CERTAIN = 6,           /* :383-409  colour and rank hinted and playable               */
+  HB_RULE_TELL_PLAYABLE_CARD_OUTER = 7,  /* :413-451  (= tell_anyone_useful_card :518-519), rank first  */
+  HB_RULE_TELL_DISPENSABLE = 8,          /* :454-514  arg = min_information_tokens                      */
+  HB_RULE_DISCARD_RANDOMLY = 9,          /* :607-614                                                    */
+  HB_RULE_PLAY_PROBABLY_SAFE = 10,       /* :617-635  threshold; arg != 0: needs more than one life     */
+  HB_RULE_DISCARD_PROBABLY_USELESS = 11, /* :638-650  threshold                                         */
+  HB_RULE_HAIL_MARY = 12,                /* :653-655  empty deck and > 1 life: play the likeliest card  */
+  HB_RULE_TELL_ANYONE_USELESS_CARD = 13, /* :522-535  needs > 1 information token                       */
+  HB_RULE_TELL_PLAYABLE_CARD = 14,       /* :570-594  rank or colour by coin                            */
+  HB_RULE_TELL_MOST_INFORMATION = 15,    /* :539-562  never returns a move in the reference (no return) */
+  HB_RULE_KINDS = 16
+};
+#define HB_MAX_RULES 16
+typedef struct hb_rule {
+  int32_t kind;
+  int32_t arg;
+  float threshold;
+} hb_rule;
+
+/* Borrowed device pointer to the env's state rows [n_games, hb_state_words()] (layout: DESIGN.md §3). */
+const uint32_t* hb_env_state(hb_env* env);
+
+/* actions_dev[g] = move uid chosen by the first rule that fires for the player to act in game g;
+ * fired_dev[g] (optional) = index of that rule, n_rules when none fired and the random-legal fallback
+ * of rule_based.py:24 was taken. rules is a HOST array of n_rules <= HB_MAX_RULES entries.            */
+int hb_rule_act(const hb_config* cfg, const uint32_t* state_rows_dev, int64_t n_games, int64_t first_game_id,
+                const hb_rule* rules, int32_t n_rules, uint64_t seed, uint64_t draw, int32_t* actions_dev,
+                int32_t* fired_dev, void* stream);
+
 /* Tuning knob for measurements: games handled per 64-lane wavefront (16, 32 or 64).    */
 int hb_env_set_games_per_wave(hb_env* env, int32_t g);
 

@@ -49,6 +49,10 @@ void orc_env_set_threads(orc_env* env, int n_threads);          /* OpenMP thread
 void orc_random_legal_actions(const int8_t* legal, int64_t n_games, int32_t n_actions, uint64_t seed,
                               uint64_t draw, int64_t first_game_id, int32_t* actions);
 
+/* ---- rule-based partners (rule_oracle.c; hanabi_agents/rule_based/ruleset.py, rule_based.py:13-25) -------- */
+void orc_rule_act(const orc_env* env, const hb_rule* rules, int32_t n_rules, uint64_t seed, uint64_t draw,
+                  int32_t* actions, int32_t* fired /* optional: index of the rule that fired, n_rules = fallback */);
+
 /* ---- sum tree ------------------------------------------------------------------------- */
 typedef struct orc_tree orc_tree;
 orc_tree* orc_tree_create(int64_t capacity);

@@ -60,6 +60,7 @@ def lib():
         L.orc_env_export_state.argtypes = [p, p]
         L.orc_env_set_threads.argtypes = [p, C.c_int]
         L.orc_random_legal_actions.argtypes = [p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, C.c_int64, p]
+        L.orc_rule_act.argtypes = [p, p, C.c_int32, C.c_uint64, C.c_uint64, p, p]
         L.orc_philox4x32.argtypes = [p, p, p]
         L.orc_shuffled_deck.argtypes = [cfgp, C.c_uint64, C.c_uint64, C.c_uint32, p]
         for f in ("orc_num_actions", "orc_obs_len", "orc_deck_size", "orc_state_words"):
@@ -82,6 +83,10 @@ def lib():
         L.orc_per_update.argtypes = [p, p, p, C.c_int64, C.c_double, p, p]
         _LIB = L
     return _LIB
+
+
+class HbRule(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("arg", C.c_int32), ("threshold", C.c_float)]
 
 
 def _ptr(a):
@@ -146,6 +151,15 @@ class OracleEnv:
 
     def illegal_count(self):
         return int(self.L.orc_env_illegal_count(self.h))
+
+    def rule_act(self, rules, seed, draw):
+        """rules: [(kind, arg, threshold)]. Returns (actions int32 [N], fired int32 [N]) of rule_oracle.c."""
+        tab = (HbRule * max(len(rules), 1))()
+        for i, (kind, arg, thr) in enumerate(rules):
+            tab[i].kind, tab[i].arg, tab[i].threshold = kind, arg, thr
+        act, fired = np.empty(self.n, np.int32), np.empty(self.n, np.int32)
+        self.L.orc_rule_act(self.h, tab, len(rules), seed, draw, _ptr(act), _ptr(fired))
+        return act, fired
 
     def export_state(self):
         rows = np.zeros((self.n, self.state_words), np.uint32)
