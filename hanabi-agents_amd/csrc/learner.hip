@@ -208,14 +208,21 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, i
 struct AdamArgs {
   float *w, *w_mu, *w_sigma;
   const float* noise;  // eps of the layer (same shape); bias noise for bias tensors
-  const float* grad;   // d loss / d (merged tensor), fp32
+  const void* grad;    // d loss / d (merged tensor): fp32 / bf16 / f16 (grad_dtype), rows grad_ld elements apart
   float *m_w, *v_w, *m_mu, *v_mu, *m_sg, *v_sg;
   const float* step;   // number of completed Adam steps (device scalar)
   void* eff;           // merged tensor in the GEMM dtype for the next forward
   long long n;
   int cols, eff_ld;    // parameter tensors are [n/cols, cols] row-major; eff rows are eff_ld >= cols elements apart
+  int grad_dtype, grad_ld;
   float lr, b1, b2, eps;
 };
+
+__device__ __forceinline__ float load_grad(const void* g, int dtype, long long i) {
+  if (dtype == 1) return __bfloat162float(static_cast<const __hip_bfloat16*>(g)[i]);
+  if (dtype == 2) return __half2float(static_cast<const __half*>(g)[i]);
+  return static_cast<const float*>(g)[i];
+}
 
 __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float b1, float b2, float bc1, float bc2s,
                                        float lr, float eps) {
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
   T* eff = static_cast<T*>(a.eff);
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const float g = a.grad[i], nz = a.noise[i];
+    const long long row = i / a.cols, col = i - row * a.cols;
+    const float g = load_grad(a.grad, a.grad_dtype, row * a.grad_ld + col), nz = a.noise[i];
     float m, v;
     m = a.m_w[i]; v = a.v_w[i];
     const float w = adam1(a.w[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
     m = a.m_sg[i]; v = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], g * nz, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
-    st<T>(eff, (i / a.cols) * a.eff_ld + (i % a.cols), w + mu + sg * nz);
+    st<T>(eff, row * a.eff_ld + col, w + mu + sg * nz);
   }
 }
 
@@ -264,7 +272,8 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
   T* eff = static_cast<T*>(a.eff);
   for (long long i = static_cast<long long>(blockIdx.x - m.first[ti]) * 256 + threadIdx.x; i < a.n;
        i += static_cast<long long>(nb) * 256) {
-    const float g = a.grad[i], nz = a.noise[i];
+    const long long row = i / a.cols, col = i - row * a.cols;
+    const float g = load_grad(a.grad, a.grad_dtype, row * a.grad_ld + col), nz = a.noise[i];
     float mm, vv;
     mm = a.m_w[i]; vv = a.v_w[i];
     const float w = adam1(a.w[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
     mm = a.m_sg[i]; vv = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], g * nz, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = mm; a.v_sg[i] = vv; a.w_sigma[i] = sg;
-    st<T>(eff, (i / a.cols) * a.eff_ld + (i % a.cols), w + mu + sg * nz);
+    st<T>(eff, row * a.eff_ld + col, w + mu + sg * nz);
   }
 }
 
@@ -370,7 +379,7 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
   if (n <= 0) return HB_OK;
   if (cols < 1 || eff_ld < cols || n % cols) return fail(HB_ERR_INVALID, "need cols >= 1, eff_ld >= cols and n a multiple of cols");
   AdamArgs a{w_dev, w_mu_dev, w_sigma_dev, noise_dev, grad_dev, m_w_dev, v_w_dev, m_mu_dev, v_mu_dev, m_sigma_dev, v_sigma_dev,
-             step_dev, eff_dev, n, cols, eff_ld, lr, beta1, beta2, eps};
+             step_dev, eff_dev, n, cols, eff_ld, 0, cols, lr, beta1, beta2, eps};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eff_dtype == 0) launch_adam<float>(a, s);
   else if (eff_dtype == 1) launch_adam<__hip_bfloat16>(a, s);
@@ -393,8 +402,10 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
         !d.v_sigma || !d.eff)
       return fail(HB_ERR_INVALID, "null pointer in tensor %d", i);
     if (d.n <= 0 || d.cols < 1 || d.eff_ld < d.cols || d.n % d.cols) return fail(HB_ERR_INVALID, "bad shape in tensor %d", i);
+    if (d.grad_dtype < 0 || d.grad_dtype > 2 || (d.grad_ld != 0 && d.grad_ld < d.cols))
+      return fail(HB_ERR_INVALID, "bad gradient dtype / row stride in tensor %d", i);
     m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
-                      step_dev, d.eff, d.n, d.cols, d.eff_ld, lr, beta1, beta2, eps};
+                      step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, d.grad_ld ? d.grad_ld : d.cols, lr, beta1, beta2, eps};
     m.first[i] = blocks;
     long long nb = (d.n + 255) / 256;
     if (nb > 1024) nb = 1024;

@@ -29,6 +29,7 @@
 
 #include "../../include/hanabi_hip.h"
 #include "common.hpp"
+#include "env_kernel.hpp"  // hb::philox4x32_10
 
 using hb::fail;
 
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ n
 
 __global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict__ nodes, long long cap, int depth,
                                                          const double* __restrict__ u, long long batch, int unit,
+                                                         unsigned long long seed, const float* __restrict__ counter,
                                                          int64_t* __restrict__ idx, double* __restrict__ prob) {
   const int lane = threadIdx.x & 63;
   const long long i = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -257,7 +259,18 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict
   const double step = batch > 1 ? (1.0 - start) / static_cast<double>(batch - 1) : 0.0;
   const double lin = (batch > 1 && i == batch - 1) ? 1.0 : static_cast<double>(i) * step + start;
   const float total = nodes[1];
-  const double ui = unit ? u[i] / static_cast<double>(batch) : u[i];  // unit: u in [0,1) is scaled to the stratum width here
+  double ui;
+  if (unit == 2) {  // drawn here: 53 random bits of Philox(seed; query, counter) -> [0, 1), scaled to the stratum width
+    const unsigned long long c = static_cast<unsigned long long>(*counter);
+    uint32_t r[4];
+    hb::philox4x32_10(static_cast<uint32_t>(i), static_cast<uint32_t>(static_cast<unsigned long long>(i) >> 32),
+                      static_cast<uint32_t>(c), static_cast<uint32_t>(c >> 32), static_cast<uint32_t>(seed),
+                      static_cast<uint32_t>(seed >> 32), r);
+    const unsigned long long bits = (static_cast<unsigned long long>(r[0] >> 5) << 26) | (r[1] >> 6);
+    ui = static_cast<double>(bits) * 0x1.0p-53 / static_cast<double>(batch);
+  } else {
+    ui = unit ? u[i] / static_cast<double>(batch) : u[i];  // unit: u in [0,1) is scaled to the stratum width here
+  }
   const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(static_cast<float>(lin - ui) * total)));
   float leaf;
   const long long k = wave_descend(nodes, cap, depth, query, lane, &leaf);
@@ -419,7 +432,19 @@ int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_u
   if (!u_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
   hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, u_dev, static_cast<long long>(batch),
-                     unit_uniforms != 0 ? 1 : 0, idx_dev, prob_dev);
+                     unit_uniforms != 0 ? 1 : 0, 0ull, static_cast<const float*>(nullptr), idx_dev, prob_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_per_sample_philox(hb_tree* t, uint64_t seed, const float* counter_dev, int64_t batch, int64_t* idx_dev,
+                         double* prob_dev, void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (batch <= 0) return HB_OK;
+  if (!counter_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, static_cast<const double*>(nullptr),
+                     static_cast<long long>(batch), 2, static_cast<unsigned long long>(seed), counter_dev, idx_dev, prob_dev);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

@@ -44,6 +44,7 @@ class ExperienceBuffer:
         self._size_t = torch.zeros((), dtype=torch.float64, device=d)
         self._size_wp = torch.zeros(2, dtype=torch.int64, device=d)   # {size, write pointer} for the n-step gather
         self.track_wp = False         # set by the agent when n_step > 1
+        self._synced = None           # (size, oldest_entry) last published by sync_size()
         self.rows_per_insert = None   # constant batch size of all inserts so far (None: nothing yet, -1: it varied)
 
     # ---- ring arithmetic (experience_buffer.py:21-24,46-81) ---------------------------------------
@@ -150,10 +151,14 @@ class ExperienceBuffer:
 
     def sync_size(self):
         """Publish the host-side `size` / write pointer to the device scalars read inside captured graphs."""
-        self._size_t.fill_(float(self.size))
+        if self._synced == (self.size, self.oldest_entry):
+            return  # nothing moved since the last call (a full ring between inserts): no launches
+        if self._synced is None or self._synced[0] != self.size:
+            self._size_t.fill_(float(self.size))
         if self.track_wp:  # only the n-step gather reads these (fill kernels, no host->device copies)
             self._size_wp[0:1].fill_(self.size)
             self._size_wp[1:2].fill_(self.oldest_entry)
+        self._synced = (self.size, self.oldest_entry)
 
     def gather_nstep_dev(self, indices: torch.Tensor, n_step: int, gamma: float):
         """n-step transitions assembled at sample time (PyTorch reference of hb_replay_gather's chain walk).

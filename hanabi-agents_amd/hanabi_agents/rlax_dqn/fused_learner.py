@@ -8,8 +8,8 @@ path in rlax_rainbow.py stays as the fp32 reference and is what runs on the CPU)
         W = w + w_mu + w_sigma*eps already materialised in the GEMM dtype
     ->  hb_c51_loss_grad: IS weights, double-Q selection, projection, cross-entropy, dLoss/dlogits
     ->  backward by hand: dW2 = H^T dlogits, dH = dlogits W2^T masked by ReLU, dW1 = X^T dH,
-        bias grads by column sums; all written into ONE flat fp32 gradient buffer
-    [-> one RCCL all-reduce of that buffer when data-parallel]
+        bias grads by column sums
+    [-> when data-parallel: packed into ONE flat fp32 buffer and all-reduced over RCCL]
     ->  hb_noisy_adam per merged tensor: routes the gradient to (w, w_mu, w_sigma) as (g, g, g*eps), Adam on
         each, and emits the next effective weight
     ->  priority update (hb_per_update)
@@ -80,6 +80,12 @@ class FusedLearner:
         self.support = agent.atoms[0].contiguous()
         self._gb2_pad = torch.zeros(self.Np, **f32)
         self._adam_tab = None
+        # Single rank: Adam reads the weight gradients straight from the (padded, GEMM-dtype) outputs of the two
+        # backward GEMMs and the bias gradients from the column-sum outputs: no pack / convert launches. With data
+        # parallelism the gradients are first packed into the flat fp32 all-reduce bucket above.
+        self.direct = agent._dp_world() == 1
+        self._gw2_out = torch.zeros(H, self.Np, dtype=self.cd, device=dev)
+        self._gw1_out = torch.zeros(self.Kp, H, dtype=self.cd, device=dev)
         self.refresh_effective()
         self.refresh_target()
 
@@ -122,18 +128,25 @@ class FusedLearner:
                                    1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
                                    K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
         hb, xb, dl = h[:B], self.x[:B], self.dlogits
-        self.g_w2.copy_(torch.mm(hb.t(), dl)[:, :self.AK])            # drop the padding columns
+        torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
         K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
-        self.g_b2.copy_(self._gb2_pad[:self.AK])
         dh = torch.ops.aten.threshold_backward(torch.mm(dl, w2.t()), hb, 0.0)
-        self.g_w1.copy_(torch.mm(xb.t(), dh)[:self.L])                # drop the padding rows
+        torch.mm(xb.t(), dh, out=self._gw1_out)                       # [Kp, H]; the padding rows are never read
         K.check(L.hb_colsum(K.dptr(dh), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
+        if not self.direct:  # pack the all-reduce bucket (fp32, unpadded)
+            self.g_w2.copy_(self._gw2_out[:, :self.AK])
+            self.g_b2.copy_(self._gb2_pad[:self.AK])
+            self.g_w1.copy_(self._gw1_out[:self.L])
         return self.td, self.w_is
 
     def _adam_table(self):
         """ctypes array describing the four merged tensors (built once: all pointers are persistent)."""
         if self._adam_tab is None:
-            grads = ((self.g_w1, self.g_b1), (self.g_w2, self.g_b2))
+            if self.direct:   # (tensor, dtype code, row stride)
+                grads = (((self._gw1_out, _DT[self.cd], self._gw1_out.shape[1]), (self.g_b1, 0, 0)),
+                         ((self._gw2_out, _DT[self.cd], self.Np), (self._gb2_pad, 0, 0)))
+            else:
+                grads = (((self.g_w1, 0, 0), (self.g_b1, 0, 0)), ((self.g_w2, 0, 0), (self.g_b2, 0, 0)))
             tab = (K.HbAdamTensor * 4)()
             k = 0
             for li, l in enumerate(self.layers):
@@ -143,7 +156,7 @@ class FusedLearner:
                     st = [self.state[(li, n)] for n in names]
                     d = tab[k]
                     d.w, d.w_mu, d.w_sigma = (p.data_ptr() for p in ps)
-                    d.noise, d.grad = noise.data_ptr(), g.data_ptr()
+                    d.noise, d.grad, d.grad_dtype, d.grad_ld = noise.data_ptr(), g[0].data_ptr(), g[1], g[2]
                     d.m_w, d.v_w = st[0][0].data_ptr(), st[0][1].data_ptr()
                     d.m_mu, d.v_mu = st[1][0].data_ptr(), st[1][1].data_ptr()
                     d.m_sigma, d.v_sigma = st[2][0].data_ptr(), st[2][1].data_ptr()

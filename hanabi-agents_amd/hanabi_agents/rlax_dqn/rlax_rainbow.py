@@ -159,6 +159,7 @@ class DQNAgent:
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
         self._beta = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._beta_host = None
         self.use_graphs = use_graphs
         self._graph1 = self._graph2 = None
         self.train_step = 0
@@ -341,7 +342,10 @@ class DQNAgent:
     def update_begin(self):
         assert self._pending is None, "update_finish() of the previous update has not been called"
         self.experience.sync_size()
-        self._beta.fill_(float(self.params.beta_is(self.train_step)))
+        beta = float(self.params.beta_is(self.train_step))
+        if beta != self._beta_host:  # device scalar read inside the captured graph: refreshed only when it changes
+            self._beta.fill_(beta)
+            self._beta_host = beta
         if self._graphs_enabled():
             if self._graph1 is None:
                 self._capture_update_graphs()
@@ -442,6 +446,11 @@ class DQNAgent:
 
     def _sample_indices(self):
         b = self.params.train_batch_size
+        if self.params.use_priority and self._fl is not None:
+            # stratified uniforms drawn inside the sampling kernel, keyed by (seed; query, optimizer step): no
+            # generator launch, and nothing for HIP-graph replay to re-seed (torch re-fills the generator's seed /
+            # offset tensors with two more launches before every replay of a graph that contains torch.rand)
+            return self.experience.sum_tree.per_sample_philox_dev(self.params.seed + 0x51ED270B, self._fl.step, b)
         if self.params.use_priority:
             u = torch.rand(b, dtype=torch.float64, device=self.device)  # scaled to [0, 1/B) inside the kernel
             return self.experience.sum_tree.per_sample_dev(u, unit=True)
@@ -608,7 +617,8 @@ class DQNAgent:
             if (passes == 1 and self._graphs_enabled() and self._graph1 is None
                     and self.experience.size >= self.params.train_batch_size):
                 self.experience.sync_size()
-                self._beta.fill_(float(self.params.beta_is(self.train_step)))
+                self._beta_host = float(self.params.beta_is(self.train_step))
+                self._beta.fill_(self._beta_host)
                 self._capture_update_graphs()
                 passes = 2
                 continue

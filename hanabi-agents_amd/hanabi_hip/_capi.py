@@ -40,7 +40,8 @@ class HbAdamTensor(C.Structure):
     """`hb_adam_tensor` of include/hanabi_hip.h."""
 
     _fields_ = [(n, C.c_void_p) for n in ("w", "w_mu", "w_sigma", "noise", "grad", "m_w", "v_w", "m_mu", "v_mu", "m_sigma",
-                                          "v_sigma", "eff")] + [("n", C.c_int64), ("cols", C.c_int32), ("eff_ld", C.c_int32)]
+                                          "v_sigma", "eff")] + [("n", C.c_int64), ("cols", C.c_int32), ("eff_ld", C.c_int32),
+                                                                                   ("grad_dtype", C.c_int32), ("grad_ld", C.c_int32)]
 
 
 class HbRule(C.Structure):
@@ -102,6 +103,7 @@ SIGNATURES = {
     "hb_tree_total": (C.c_int, [_P, _P, _P]),
     "hb_tree_error_count": (C.c_int, [_P, C.POINTER(_I64)]),
     "hb_per_sample": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "hb_per_sample_philox": (C.c_int, [_P, _U64, _P, _I64, _P, _P, _P]),
     "hb_per_update": (C.c_int, [_P, _P, _P, _I64, _F64, _P, _P, _P]),
     "hb_obs_cast": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "hb_policy_act": (C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _I32, C.c_float, _U64, _U64, _I64, _P, _P, _P]),

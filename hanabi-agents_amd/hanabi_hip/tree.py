@@ -69,6 +69,15 @@ class SumTree:
         K.check(self.L.hb_per_sample(self.h, K.dptr(u), b, 1 if unit else 0, K.dptr(idx), K.dptr(prob), K.current_stream()))
         return idx, prob
 
+    def per_sample_philox_dev(self, seed, counter_dev, batch, idx_out=None, prob_out=None):
+        """per_sample_dev with the stratified uniforms drawn inside the kernel from Philox(seed; i, counter)."""
+        assert counter_dev.dtype == torch.float32 and counter_dev.is_cuda
+        idx = idx_out if idx_out is not None else torch.empty(batch, dtype=torch.int64, device=self.device)
+        prob = prob_out if prob_out is not None else torch.empty(batch, dtype=torch.float64, device=self.device)
+        K.check(self.L.hb_per_sample_philox(self.h, int(seed), K.dptr(counter_dev), int(batch), K.dptr(idx), K.dptr(prob),
+                                            K.current_stream()))
+        return idx, prob
+
     def per_update_dev(self, idx, td, alpha, max_prio_dev, min_prio_dev):
         assert idx.dtype == torch.int64 and td.dtype == torch.float32
         K.check(self.L.hb_per_update(self.h, K.dptr(idx), K.dptr(td), idx.numel(), float(alpha), K.dptr(max_prio_dev),

@@ -255,6 +255,12 @@ int hb_tree_error_count(hb_tree* t, int64_t* out); /* synchronises the stream */
  * u_i is in [0, 1) and is divided by B inside the kernel (saves the caller a launch).    */
 int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_uniforms, int64_t* idx_dev,
                   double* prob_dev, void* stream);
+/* The same with the uniforms drawn inside the kernel (no generator launch, nothing for a captured graph to
+ * re-seed): u_i = bits53(Philox4x32-10(key = seed; counter = (i, uint64(*counter_dev)))) * 2^-53 / B with
+ * bits53 = (word0 >> 5) << 26 | word1 >> 6. counter_dev is any device scalar that changes between calls (the
+ * learner passes its optimizer step count).                                                         */
+int hb_per_sample_philox(hb_tree* t, uint64_t seed, const float* counter_dev, int64_t batch, int64_t* idx_dev,
+                         double* prob_dev, void* stream);
 /* hb_per_update: p_i = (|td_i| + 1e-10)^alpha (double pow, rounded to float as the
  * pybind float conversion does), max/min priority tracked in device scalars
  * (priority_buffer.py:48-52), then hb_tree_update.                                      */
@@ -337,11 +343,12 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
 typedef struct hb_adam_tensor {
   float *w, *w_mu, *w_sigma;
   const float* noise;
-  const float* grad;
+  const void* grad;      /* gradient of the merged tensor, dtype grad_dtype (0 f32, 1 bf16, 2 f16): e.g. the GEMM output itself */
   float *m_w, *v_w, *m_mu, *v_mu, *m_sigma, *v_sigma;
   void* eff;
   int64_t n;
   int32_t cols, eff_ld;
+  int32_t grad_dtype, grad_ld; /* grad rows are grad_ld >= cols elements apart (0: contiguous)                       */
 } hb_adam_tensor;
 int hb_noisy_adam_multi(const hb_adam_tensor* tensors /* host array of device pointers */, int32_t count,
                         const float* step_dev, int32_t eff_dtype, float lr, float beta1, float beta2, float eps,

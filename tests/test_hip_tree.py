@@ -167,3 +167,31 @@ def test_learner_sized_per_cycle_at_full_capacity():
         omx, omn = o.per_update(oi, td, 0.6, omx, omn)
     assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:])
     assert float(mx.cpu()[0]) == np.float32(omx) and float(mn.cpu()[0]) == np.float32(omn)
+
+
+def test_per_sample_philox_draws_match_host_philox():
+    """hb_per_sample_philox == hb_per_sample / the oracle on uniforms rebuilt on the host from the same Philox
+    words (bits53 = word0>>5 << 26 | word1>>6), for two counter values; strata stay stratified."""
+    import torch
+
+    cap, batch, seed = 4096, 256, 0xABCDEF12345
+    t, o = T(cap), O.OracleTree(cap)
+    rng = np.random.default_rng(3)
+    vals = rng.random(cap).astype(np.float32) ** 2
+    t.update_dev(dev(np.arange(cap), np.int64), dev(vals, np.float32))
+    o.update(np.arange(cap), vals)
+    for counter in (0.0, 7.0, 123456.0):
+        c = torch.tensor(counter, dtype=torch.float32, device="cuda")
+        gi, gp = t.per_sample_philox_dev(seed, c, batch)
+        u = np.empty(batch, np.float64)
+        for i in range(batch):
+            w = O.philox([i, 0, int(counter), 0], [seed & 0xFFFFFFFF, seed >> 32])
+            u[i] = float((int(w[0]) >> 5) << 26 | (int(w[1]) >> 6)) * 2.0 ** -53 / batch
+        assert (u >= 0).all() and (u < 1.0 / batch).all()
+        oi, op = o.per_sample(u)
+        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gp.cpu().numpy(), op)
+        hi, hp = t.per_sample_dev(dev(u, np.float64))
+        assert torch.equal(hi, gi) and torch.equal(hp, gp)
+    a, _ = t.per_sample_philox_dev(seed, torch.tensor(1.0, device="cuda"), batch)
+    b, _ = t.per_sample_philox_dev(seed, torch.tensor(2.0, device="cuda"), batch)
+    assert not torch.equal(a, b)
