@@ -107,10 +107,11 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
                                                   const float* __restrict__ beta_dev, const float* __restrict__ disc, int mask_terminal,
                                                   const float* __restrict__ support, int B, int A, int K, int rs,
                                                   float* __restrict__ td_out, float* __restrict__ w_out,
-                                                  T* __restrict__ dlogits) {
+                                                  T* __restrict__ dlogits, float* __restrict__ counter) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wave;
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1.f;  // nothing else touches it during this kernel
   if (b >= B) return;
   const int AK = A * K;
   float* sel = lds + wave * (AK + 64);
@@ -204,6 +205,34 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, i
   }
 }
 
+// ReLU backward fused with the bias gradient: dy[i, j] <- act[i, j] > 0 ? dy[i, j] : 0 (aten::threshold_backward
+// with threshold 0 on the post-activation), out[j] = sum_i of the masked values. Same tiling and summation order as
+// colsum_kernel.
+template <typename T>
+__global__ __launch_bounds__(1024) void relu_bwd_colsum_kernel(T* __restrict__ dy, const T* __restrict__ act, int rows, int cols,
+                                                               float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols) {
+#pragma unroll 16
+    for (int i = rg; i < rows; i += 16) {
+      const long long k = static_cast<long long>(i) * cols + c;
+      const float g = ld<T>(act, k) > 0.f ? ld<T>(dy, k) : 0.f;
+      st<T>(dy, k, g);
+      s += g;
+    }
+  }
+  part[rg][l] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][l];
+    out[c] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct AdamArgs {
   float *w, *w_mu, *w_sigma;
@@ -216,6 +245,7 @@ struct AdamArgs {
   int cols, eff_ld;    // parameter tensors are [n/cols, cols] row-major; eff rows are eff_ld >= cols elements apart
   int grad_dtype, grad_ld;
   float lr, b1, b2, eps;
+  float step_offset;   // this step's number t = *step + step_offset
 };
 
 __device__ __forceinline__ float load_grad(const void* g, int dtype, long long i) {
@@ -233,7 +263,7 @@ __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, flo
 
 template <typename T>
 __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
-  const float t = *a.step + 1.f;
+  const float t = *a.step + a.step_offset;
   const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
   T* eff = static_cast<T*>(a.eff);
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n;
@@ -267,7 +297,7 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
   while (ti + 1 < m.count && static_cast<int>(blockIdx.x) >= m.first[ti + 1]) ++ti;
   const AdamArgs& a = m.t[ti];
   const int nb = m.first[ti + 1] - m.first[ti];
-  const float t = *a.step + 1.f;
+  const float t = *a.step + a.step_offset;
   const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
   T* eff = static_cast<T*>(a.eff);
   for (long long i = static_cast<long long>(blockIdx.x - m.first[ti]) * 256 + threadIdx.x; i < a.n;
@@ -331,7 +361,8 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
-                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream) {
+                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, float* update_counter_dev,
+                     void* stream) {
   if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev || !disc_dev ||
       !support_dev || !td_dev || !w_dev || !dlogits_dev)
     return fail(HB_ERR_INVALID, "null argument");
@@ -345,7 +376,8 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
 #define HB_C51(T)                                                                                                       \
   hipLaunchKernelGGL((c51_kernel<T>), grid, block, lds, s, static_cast<const T*>(logits_online_dev),                    \
                      static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, disc_dev, \
-                     mask_terminal, support_dev, B, n_actions, n_atoms, row_stride, td_dev, w_dev, static_cast<T*>(dlogits_dev))
+                     mask_terminal, support_dev, B, n_actions, n_atoms, row_stride, td_dev, w_dev, static_cast<T*>(dlogits_dev),       \
+                     update_counter_dev)
   if (dtype == 0) HB_C51(float);
   else if (dtype == 1) HB_C51(__hip_bfloat16);
   else if (dtype == 2) HB_C51(__half);
@@ -379,7 +411,7 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
   if (n <= 0) return HB_OK;
   if (cols < 1 || eff_ld < cols || n % cols) return fail(HB_ERR_INVALID, "need cols >= 1, eff_ld >= cols and n a multiple of cols");
   AdamArgs a{w_dev, w_mu_dev, w_sigma_dev, noise_dev, grad_dev, m_w_dev, v_w_dev, m_mu_dev, v_mu_dev, m_sigma_dev, v_sigma_dev,
-             step_dev, eff_dev, n, cols, eff_ld, 0, cols, lr, beta1, beta2, eps};
+             step_dev, eff_dev, n, cols, eff_ld, 0, cols, lr, beta1, beta2, eps, 1.f};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eff_dtype == 0) launch_adam<float>(a, s);
   else if (eff_dtype == 1) launch_adam<__hip_bfloat16>(a, s);
@@ -389,8 +421,23 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
   return HB_OK;
 }
 
-int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const float* step_dev, int32_t eff_dtype, float lr,
-                        float beta1, float beta2, float eps, void* stream) {
+int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev,
+                       void* stream) {
+  if (!dy_dev || !act_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (rows <= 0 || cols <= 0) return HB_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>((cols + 63) / 64)), block(1024);
+  const int r = static_cast<int>(rows), c = static_cast<int>(cols);
+  if (dtype == 0) hipLaunchKernelGGL((relu_bwd_colsum_kernel<float>), grid, block, 0, s, static_cast<float*>(dy_dev), static_cast<const float*>(act_dev), r, c, out_dev);
+  else if (dtype == 1) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__hip_bfloat16>), grid, block, 0, s, static_cast<__hip_bfloat16*>(dy_dev), static_cast<const __hip_bfloat16*>(act_dev), r, c, out_dev);
+  else if (dtype == 2) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__half>), grid, block, 0, s, static_cast<__half*>(dy_dev), static_cast<const __half*>(act_dev), r, c, out_dev);
+  else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const float* step_dev, float step_offset, int32_t eff_dtype,
+                        float lr, float beta1, float beta2, float eps, void* stream) {
   if (!tensors || !step_dev) return fail(HB_ERR_INVALID, "null argument");
   if (count < 1 || count > 8) return fail(HB_ERR_INVALID, "count must be 1..8");
   AdamMulti m{};
@@ -405,7 +452,7 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
     if (d.grad_dtype < 0 || d.grad_dtype > 2 || (d.grad_ld != 0 && d.grad_ld < d.cols))
       return fail(HB_ERR_INVALID, "bad gradient dtype / row stride in tensor %d", i);
     m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
-                      step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, d.grad_ld ? d.grad_ld : d.cols, lr, beta1, beta2, eps};
+                      step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, d.grad_ld ? d.grad_ld : d.cols, lr, beta1, beta2, eps, step_offset};
     m.first[i] = blocks;
     long long nb = (d.n + 255) / 256;
     if (nb > 1024) nb = 1024;

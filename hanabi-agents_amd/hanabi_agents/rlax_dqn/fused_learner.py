@@ -126,13 +126,13 @@ class FusedLearner:
         K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
                                    1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
-                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), s))
+                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step), s))
         hb, xb, dl = h[:B], self.x[:B], self.dlogits
         torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
         K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
-        dh = torch.ops.aten.threshold_backward(torch.mm(dl, w2.t()), hb, 0.0)
+        dh = torch.mm(dl, w2.t())                                      # masked by the ReLU in place, with its column sums
+        K.check(L.hb_relu_bwd_colsum(K.dptr(dh), K.dptr(hb), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         torch.mm(xb.t(), dh, out=self._gw1_out)                       # [Kp, H]; the padding rows are never read
-        K.check(L.hb_colsum(K.dptr(dh), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         if not self.direct:  # pack the all-reduce bucket (fp32, unpadded)
             self.g_w2.copy_(self._gw2_out[:, :self.AK])
             self.g_b2.copy_(self._gb2_pad[:self.AK])
@@ -167,9 +167,9 @@ class FusedLearner:
 
     def part2(self):
         p = self.agent.params
-        K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), _DT[self.cd], float(p.learning_rate),
-                                            0.9, 0.999, 3.125e-5, K.current_stream()))
-        self.step.add_(1.0)
+        # self.step was advanced by this update's loss kernel (part1): it already is this step's number
+        K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
+                                            float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
 
     def loss(self):
         return torch.mean(self.td * self.w_is)

@@ -319,11 +319,14 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
  *   Outputs: td_dev [B] (cross-entropy "TD", its |.| is the new priority), w_dev [B] (IS
  *   weights (1/P)^beta / max), dlogits_dev [B, A*K] = d mean(td * w) / d online(obs_tm1).
  *   disc_dev [B]: per-sample discount (gamma for 1-step, gamma^m for n-step transitions).
- *   mask_terminal != 0 multiplies the discount by (1 - term) (off = the reference, App. C-5).   */
+ *   mask_terminal != 0 multiplies the discount by (1 - term) (off = the reference, App. C-5).
+ *   update_counter_dev: NULL, or a device float that this launch increments by one: a per-update counter for the
+ *   caller (the optimizer's step number, see hb_noisy_adam_multi's step_offset) without a launch of its own. */
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
-                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, void* stream);
+                     int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev,
+                     float* update_counter_dev, void* stream);
 
 /* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:
  * the column sums of dLoss/dlogits and of dLoss/dhidden). x_dev [rows, cols] contiguous.        */
@@ -350,9 +353,17 @@ typedef struct hb_adam_tensor {
   int32_t cols, eff_ld;
   int32_t grad_dtype, grad_ld; /* grad rows are grad_ld >= cols elements apart (0: contiguous)                       */
 } hb_adam_tensor;
+/* This step's number (Adam's bias correction) is t = *step_dev + step_offset: 1 when step_dev counts completed steps
+ * (hb_noisy_adam's convention), 0 when it already counts the running one (see hb_c51_loss_grad's counter).      */
 int hb_noisy_adam_multi(const hb_adam_tensor* tensors /* host array of device pointers */, int32_t count,
-                        const float* step_dev, int32_t eff_dtype, float lr, float beta1, float beta2, float eps,
-                        void* stream);
+                        const float* step_dev, float step_offset, int32_t eff_dtype, float lr, float beta1, float beta2,
+                        float eps, void* stream);
+
+/* ReLU backward fused with the bias gradient (the `jax.grad` of relu + the bias add, rlax_rainbow.py:203-206 through
+ * noisy_mlp.py:176-185): dy_dev [rows, cols] is masked in place where act_dev (the post-activation) is <= 0, and
+ * out_dev[j] = sum over rows of the masked values (fp32, fixed order).                                          */
+int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -236,3 +236,38 @@ def test_fused_learner_equals_autograd_learner(mask, priority, n_step):
     w_eff, _ = fused.online.layers[0].effective()
     got = fused._effective_weights()[0][0].float()
     assert torch.allclose(got[:obs_len], w_eff, rtol=1e-2, atol=1e-3) and not got[obs_len:].any()   # K padding stays zero
+
+
+def test_relu_backward_with_column_sums_and_update_counter():
+    """hb_relu_bwd_colsum == aten::threshold_backward + column sums (fp32, fixed order); the loss kernel
+    advances the learner's step counter exactly once per update."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip import _capi as K
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for dt, code in ((torch.bfloat16, 1), (torch.float32, 0), (torch.float16, 2)):
+        dy = torch.randn(256, 512, device="cuda", generator=g).to(dt)
+        act = torch.relu(torch.randn(256, 512, device="cuda", generator=g)).to(dt)
+        want = torch.ops.aten.threshold_backward(dy, act, 0.0)
+        out = torch.empty(512, device="cuda")
+        got = dy.clone()
+        K.check(K.lib().hb_relu_bwd_colsum(K.dptr(got), K.dptr(act), code, 256, 512, K.dptr(out), K.current_stream()))
+        assert torch.equal(got, want)
+        ref = torch.empty(512, device="cuda")
+        K.check(K.lib().hb_colsum(K.dptr(want), code, 256, 512, K.dptr(ref), K.current_stream()))
+        assert torch.equal(out, ref) and torch.allclose(out, want.float().sum(0), rtol=1e-4, atol=1e-3)
+
+    n = 64
+    params = RlaxRainbowParams(train_batch_size=32, experience_buffer_size=256, layers=[32])
+    a = DQNAgent(ObservationSpec((n, 171)), ActionSpec(11), params, device="cuda")
+    obs = (torch.rand(n, 171, device="cuda", generator=g) < 0.3).to(torch.int8)
+    legal = torch.ones(n, 11, dtype=torch.int8, device="cuda")
+    a.add_experience_first((None, (obs, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+    a.add_experience((None, (obs, legal)), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.ones(n, device="cuda"),
+                     torch.ones(n, dtype=torch.int8, device="cuda"))
+    for _ in range(4):
+        a.update()
+    warm = 3  # eager warm-up updates run by the graph capture (rlax_rainbow.py: _capture_update_graphs)
+    assert a._fl.step.item() == 4 + warm and a.train_step == 4
