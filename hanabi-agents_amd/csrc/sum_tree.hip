@@ -11,7 +11,9 @@
 // result does not depend on update order.
 //
 // Kernels (all latency-bound: a handful of dependent L2 round trips):
-//   update_small   n <= 1024 (the learner's B=256 priority update): ONE workgroup de-duplicates
+//   update_chunks  n <= 1024 on a deep tree (the learner's B=256 priority update at cap 2^19): one workgroup per
+//                  touched 1024-leaf subtree applies its entries and rebuilds it through LDS; then rebuild_top.
+//   update_small   n <= 1024 on a shallow tree: ONE workgroup de-duplicates
 //                  (last occurrence wins, the sequential order of sum_tree.h:38-44), writes the
 //                  leaves and re-sums their ancestors level by level. Optionally fuses
 //                  p = (|td|+1e-10)^alpha and the running max/min (priority_buffer.py:48-52).
@@ -25,6 +27,7 @@
 //                  with v_readlane, so cap = 2^19 costs 4 dependent loads instead of 19.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <new>
 
 #include "../../include/hanabi_hip.h"
@@ -42,6 +45,7 @@ struct hb_tree {
   unsigned long long* errors;
   float* scratch;     // large per_update: transformed priorities
   long long scratch_n;
+  bool single_wg;     // measurements only (env HB_TREE_UPDATE_PATH=single at creation): force update_small
 };
 
 namespace {
@@ -144,6 +148,120 @@ __global__ __launch_bounds__(256) void chunk_kernel(float* __restrict__ nodes, l
   // subtree root is global node (cap + leaf0) / chunk; local node m at level width w maps to global base + offset
   for (int w = chunk >> 1; w >= 1; w >>= 1) {
     for (int j = threadIdx.x; j < w; j += 256) {
+      const float v = s[2 * (w + j)] + s[2 * (w + j) + 1];
+      s[w + j] = v;
+      nodes[(cap + leaf0) / (chunk / w) + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update_chunks: small update (n <= 1024) of a deep tree. Workgroup i looks at entry i: if no earlier entry falls
+// into the same 1024-leaf subtree it OWNS that subtree — applies every entry that falls into it (last occurrence
+// wins) and rebuilds the subtree's 10 levels through LDS, one load round and one store round instead of a dependent
+// HBM round trip per level. rebuild_top then re-sums the levels above. Workgroup n (the extra one) keeps the
+// running max / min priority and counts out-of-range indices. Result == update_small (every inner node is
+// fl(left + right) of its children either way).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void update_chunks_kernel(float* __restrict__ nodes, long long cap, int chunk,
+                                                            const int64_t* __restrict__ idx, const float* __restrict__ val,
+                                                            int n, int per_mode, double alpha, float* max_prio,
+                                                            float* min_prio, unsigned long long* errors) {
+  __shared__ float s[2048];
+  __shared__ __attribute__((aligned(16))) int s_idx[SMALL_MAX + 4];
+  __shared__ float s_red[2][4];
+  const int tid = threadIdx.x;
+  auto transformed = [&](float v) {
+    // (priorities + 1e-10) ** alpha on float32 data (priority_buffer.py:49): float add, the power in double
+    // rounded once to float
+    return per_mode ? static_cast<float>(pow(static_cast<double>(fabsf(v) + 1e-10f), alpha)) : v;
+  };
+  if (static_cast<int>(blockIdx.x) == n) {
+    float mx = -INFINITY, mn = INFINITY;
+    int bad = 0;
+    for (int j = tid; j < n; j += 256) {
+      const long long k = idx[j];
+      if (k < 0 || k >= cap) ++bad;
+      if (per_mode) {  // over ALL transformed priorities, also those of ignored indices (priority_buffer.py:50-51)
+        const float p = transformed(val[j]);
+        mx = fmaxf(mx, p);
+        mn = fminf(mn, p);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      mn = fminf(mn, __shfl_xor(mn, o));
+      bad += __shfl_xor(bad, o);
+    }
+    if ((tid & 63) == 0) {
+      s_red[0][tid >> 6] = mx;
+      s_red[1][tid >> 6] = mn;
+      if (bad) atomicAdd(errors, static_cast<unsigned long long>(bad));
+    }
+    __syncthreads();
+    if (per_mode && tid == 0) {
+      for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, s_red[0][w]); mn = fminf(mn, s_red[1][w]); }
+      if (max_prio && mx > *max_prio) *max_prio = mx;
+      if (min_prio && mn < *min_prio) *min_prio = mn;
+    }
+    return;
+  }
+  // one round trip for everything this workgroup may need: all indices (as chunk-local ids later) and values
+  __shared__ int s_chunk[SMALL_MAX];
+  __shared__ int s_stamp[1024];
+  long long my_idx[4];
+  float my_val[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = tid + 256 * r;
+    my_idx[r] = j < n ? idx[j] : -1;
+    my_val[r] = j < n ? val[j] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = tid + 256 * r;
+    const bool ok = my_idx[r] >= 0 && my_idx[r] < cap;
+    if (j < n) {
+      s_chunk[j] = ok ? static_cast<int>(my_idx[r] / chunk) : -1;
+      s_idx[j] = ok ? static_cast<int>(my_idx[r] % chunk) : -1;
+    }
+  }
+  for (int j = tid; j < chunk; j += 256) s_stamp[j] = 0;
+  __syncthreads();
+  const int my_chunk = s_chunk[blockIdx.x];
+  if (my_chunk < 0) return;
+  // do I own this subtree (no earlier entry falls into it)? and which entry wrote each of its leaves last?
+  int earlier = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = tid + 256 * r;
+    if (j < n && s_chunk[j] == my_chunk) {
+      if (j < static_cast<int>(blockIdx.x)) earlier = 1;
+      atomicMax(&s_stamp[s_idx[j]], j + 1);  // last occurrence wins (the sequential order of sum_tree.h:38-44)
+    }
+  }
+  const long long leaf0 = static_cast<long long>(my_chunk) * chunk;
+  float keep[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) keep[r] = tid + 256 * r < chunk ? nodes[cap + leaf0 + tid + 256 * r] : 0.f;
+  if (__syncthreads_or(earlier)) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (tid + 256 * r < chunk) s[chunk + tid + 256 * r] = keep[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = tid + 256 * r;
+    if (j < n && s_chunk[j] == my_chunk && s_stamp[s_idx[j]] == j + 1) {
+      const float v = transformed(my_val[r]);
+      s[chunk + s_idx[j]] = v;
+      nodes[cap + leaf0 + s_idx[j]] = v;
+    }
+  }
+  __syncthreads();
+  for (int w = chunk >> 1; w >= 1; w >>= 1) {
+    for (int j = tid; j < w; j += 256) {
       const float v = s[2 * (w + j)] + s[2 * (w + j) + 1];
       s[w + j] = v;
       nodes[(cap + leaf0) / (chunk / w) + j] = v;
@@ -325,6 +443,10 @@ int hb_tree_create(int64_t capacity, hb_tree** out) {
   t->stamp = nullptr;
   t->scratch = nullptr;
   t->scratch_n = 0;
+  {
+    const char* path = getenv("HB_TREE_UPDATE_PATH");
+    t->single_wg = path && path[0] == 's';
+  }
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->nodes), 2 * cap * sizeof(float)), delete t);
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->errors), 8), { (void)hipFree(t->nodes); delete t; });
   HB_HIP_OR(hipMemset(t->nodes, 0, 2 * cap * sizeof(float)), hb_tree_destroy(t));
@@ -349,6 +471,17 @@ float* hb_tree_nodes(hb_tree* t) { return t ? t->nodes : nullptr; }
 static int update_impl(hb_tree* t, const int64_t* idx, const float* val, int64_t n, int per_mode, double alpha,
                        float* max_prio, float* min_prio, hipStream_t s) {
   if (n <= 0) return HB_OK;
+  // (measured at cap 2^19, scripts/tree_probe.py: one workgroup 7.9 / 12.6 / 20.0 / 68 us at n = 32 / 128 / 256 / 1024;
+  //  per-subtree workgroups 11-12 us flat)
+  if (n >= 96 && n <= SMALL_MAX && t->cap >= 4 * static_cast<long long>(t->chunk) && !t->single_wg) {
+    hipLaunchKernelGGL(update_chunks_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
+                       idx, val, static_cast<int>(n), per_mode, alpha, max_prio, min_prio, t->errors);
+    const int ntop = static_cast<int>(t->cap / t->chunk);
+    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
+                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+  }
   if (n <= SMALL_MAX) {
     const int threads = n <= 256 ? 256 : (n <= 512 ? 512 : 1024);
     hipLaunchKernelGGL(update_small_kernel, dim3(1), dim3(threads), 0, s, t->nodes, t->cap, t->depth, idx, val,

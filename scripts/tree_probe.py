@@ -2,7 +2,9 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hanabi-agents_amd"))
 import hanabi_hip
+os.environ["HB_TREE_UPDATE_PATH"] = sys.argv[1] if len(sys.argv) > 1 else "chunks"   # "single": the one-workgroup path
 t = hanabi_hip.SumTree(2**19)
+print("small-update path:", os.environ["HB_TREE_UPDATE_PATH"])
 mx = torch.tensor([0.6], device="cuda"); mn = mx.clone()
 t.fill_range_dev(0, 300000, mx)
 def tm(fn, reps=50):

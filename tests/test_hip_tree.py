@@ -89,6 +89,40 @@ def test_out_of_range_indices_are_ignored_and_counted():
     assert t.get_values([5, 100]) == [5.0, 0.0]
 
 
+def test_small_update_of_a_deep_tree_duplicates_and_bad_indices():
+    """The per-subtree path (update_chunks): many entries in one 1024-leaf subtree with repeated leaves, entries
+    at subtree borders, out-of-range indices, n from 1 to 1024; PER mode tracks max / min over ALL entries."""
+    import torch
+
+    cap = 2 ** 15
+    rng = np.random.default_rng(11)
+    t, o = T(cap), O.OracleTree(cap)
+    bad_total = 0
+    for n in (1, 2, 63, 256, 257, 1000, 1024):
+        idx = np.concatenate([rng.integers(2048, 3072, n // 2),             # one subtree, plenty of duplicates
+                              rng.choice([0, 1023, 1024, 2047, cap - 1], n - n // 2)]).astype(np.int64)
+        rng.shuffle(idx)
+        if n >= 63:
+            idx[5], idx[17] = -3, cap                                        # ignored, counted
+            bad_total += 2
+        val = (rng.random(n).astype(np.float32) + 0.01) * 2
+        t.update_dev(dev(idx, np.int64), dev(val, np.float32))
+        o.update(idx, val)
+        assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:]), n
+    assert t.error_count() == bad_total
+    mx = torch.tensor([0.6], dtype=torch.float32, device="cuda")
+    mn = mx.clone()
+    omx = omn = float(np.float32(0.6))
+    for n in (5, 256, 700):
+        idx = rng.integers(0, cap, n).astype(np.int64)
+        idx[: n // 3] = idx[n // 3: 2 * (n // 3)]                            # repeated leaves with different values
+        td = (rng.standard_normal(n) * 3).astype(np.float32)
+        t.per_update_dev(dev(idx, np.int64), dev(td, np.float32), 0.6, mx, mn)
+        omx, omn = o.per_update(idx, td, 0.6, omx, omn)
+        assert np.array_equal(t.nodes().cpu().numpy()[1:], o.nodes()[1:]), n
+        assert float(mx.cpu()[0]) == np.float32(omx) and float(mn.cpu()[0]) == np.float32(omn)
+
+
 @pytest.mark.parametrize("cap,start,n", [(8, 6, 4), (2 ** 19, 2 ** 19 - 100, 32768), (2 ** 19, 0, 32768),
                                          (4096, 1000, 4096), (1024, 1023, 2), (512, 10, 100)])
 def test_fill_range_matches_oracle(cap, start, n):
