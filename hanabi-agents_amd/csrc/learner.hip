@@ -16,6 +16,7 @@
 //                    re-forms effective weights and the actor re-uses them
 // The GEMMs between them stay in hipBLASLt (torch.addmm / torch.mm on MFMA).
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -256,9 +257,14 @@ __device__ __forceinline__ float load_grad(const void* g, int dtype, long long i
 
 __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float b1, float b2, float bc1, float bc2s,
                                        float lr, float eps) {
-  m = b1 * m + (1.f - b1) * g;
-  v = b2 * v + (1.f - b2) * g * g;
-  return p - (lr / bc1) * m / (sqrtf(v) / bc2s + eps);  // torch.optim.Adam / optix.adam: eps outside the sqrt
+  // explicit roundings (no compiler-chosen FMA contraction): the scalar and the 4-wide kernels must agree bit for bit
+  m = __fmaf_rn(b1, m, __fmul_rn(1.f - b1, g));
+  v = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(1.f - b2, g), g));
+  // torch.optim.Adam / optix.adam: eps outside the sqrt
+  return __fsub_rn(p, __fdiv_rn(__fmul_rn(lr / bc1, m), __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), eps)));
+}
+__device__ __forceinline__ float merged(float w, float mu, float sg, float nz) {  // W = w + w_mu + w_sigma * noise
+  return __fadd_rn(__fadd_rn(w, mu), __fmul_rn(sg, nz));
 }
 
 template <typename T>
@@ -278,9 +284,9 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
     const float mu = adam1(a.w_mu[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_mu[i] = m; a.v_mu[i] = v; a.w_mu[i] = mu;
     m = a.m_sg[i]; v = a.v_sg[i];
-    const float sg = adam1(a.w_sigma[i], g * nz, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    const float sg = adam1(a.w_sigma[i], __fmul_rn(g, nz), m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
-    st<T>(eff, row * a.eff_ld + col, w + mu + sg * nz);
+    st<T>(eff, row * a.eff_ld + col, merged(w, mu, sg, nz));
   }
 }
 
@@ -290,6 +296,63 @@ struct AdamMulti {
   int first[9];
   int count;
 };
+
+// four consecutive elements per thread (one 16-byte access per array); every tensor has cols % 4 == 0, n < 2^31 and
+// 16-byte aligned rows (checked on the host), so a group of four never straddles a row
+template <typename T>
+__device__ __forceinline__ void load_grad4(const void* g, int dtype, long long i, float out[4]) {
+  if (dtype == 0) {
+    const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(g) + i);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else if (dtype == 1) {
+    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __hip_bfloat16*>(g) + i);
+    out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  } else {
+    const __half* h = static_cast<const __half*>(g) + i;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = __half2float(h[k]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void noisy_adam_multi4_kernel(const AdamMulti m) {
+  int ti = 0;
+  while (ti + 1 < m.count && static_cast<int>(blockIdx.x) >= m.first[ti + 1]) ++ti;
+  const AdamArgs& a = m.t[ti];
+  const int nb = m.first[ti + 1] - m.first[ti];
+  const float t = *a.step + a.step_offset;
+  const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
+  T* eff = static_cast<T*>(a.eff);
+  const int n4 = static_cast<int>(a.n >> 2), c4 = a.cols >> 2;
+  for (int q = (static_cast<int>(blockIdx.x) - m.first[ti]) * 256 + static_cast<int>(threadIdx.x); q < n4; q += nb * 256) {
+    const int row = q / c4, col = (q - row * c4) << 2;
+    const long long i = static_cast<long long>(q) << 2;
+    float g[4];
+    load_grad4<T>(a.grad, a.grad_dtype, static_cast<long long>(row) * a.grad_ld + col, g);
+    const float4 nz4 = *reinterpret_cast<const float4*>(a.noise + i);
+    const float nz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
+    float res[3][4];
+    auto one = [&](float* p, float* mp, float* vp, int which) {
+      float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(mp + i), vv = *reinterpret_cast<float4*>(vp + i);
+      float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pa[k] = adam1(pa[k], which == 2 ? __fmul_rn(g[k], nz[k]) : g[k], ma[k], va[k], a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+        res[which][k] = pa[k];
+      }
+      *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      *reinterpret_cast<float4*>(mp + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+      *reinterpret_cast<float4*>(vp + i) = make_float4(va[0], va[1], va[2], va[3]);
+    };
+    one(a.w, a.m_w, a.v_w, 0);
+    one(a.w_mu, a.m_mu, a.v_mu, 1);
+    one(a.w_sigma, a.m_sg, a.v_sg, 2);
+    const long long e = static_cast<long long>(row) * a.eff_ld + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st<T>(eff, e + k, merged(res[0][k], res[1][k], res[2][k], nz[k]));
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m) {
@@ -312,9 +375,9 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
     const float mu = adam1(a.w_mu[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_mu[i] = mm; a.v_mu[i] = vv; a.w_mu[i] = mu;
     mm = a.m_sg[i]; vv = a.v_sg[i];
-    const float sg = adam1(a.w_sigma[i], g * nz, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+    const float sg = adam1(a.w_sigma[i], __fmul_rn(g, nz), mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = mm; a.v_sg[i] = vv; a.w_sigma[i] = sg;
-    st<T>(eff, row * a.eff_ld + col, w + mu + sg * nz);
+    st<T>(eff, row * a.eff_ld + col, merged(w, mu, sg, nz));
   }
 }
 
@@ -443,6 +506,15 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
   AdamMulti m{};
   m.count = count;
   int blocks = 0;
+  bool vec4 = true;  // four elements per thread when every tensor allows 16-byte accesses
+  for (int i = 0; i < count; ++i) {
+    const hb_adam_tensor& d = tensors[i];
+    const int gl = d.grad_ld ? d.grad_ld : d.cols;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    vec4 = vec4 && d.cols % 4 == 0 && d.n % 4 == 0 && d.n < (1LL << 31) && d.eff_ld % 4 == 0 && gl % 4 == 0 && al16(d.w) &&
+           al16(d.w_mu) && al16(d.w_sigma) && al16(d.noise) && al16(d.grad) && al16(d.m_w) && al16(d.v_w) && al16(d.m_mu) &&
+           al16(d.v_mu) && al16(d.m_sigma) && al16(d.v_sigma);
+  }
   for (int i = 0; i < count; ++i) {
     const hb_adam_tensor& d = tensors[i];
     if (!d.w || !d.w_mu || !d.w_sigma || !d.noise || !d.grad || !d.m_w || !d.v_w || !d.m_mu || !d.v_mu || !d.m_sigma ||
@@ -454,13 +526,16 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
     m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
                       step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, d.grad_ld ? d.grad_ld : d.cols, lr, beta1, beta2, eps, step_offset};
     m.first[i] = blocks;
-    long long nb = (d.n + 255) / 256;
+    long long nb = ((vec4 ? d.n / 4 : d.n) + 255) / 256;
     if (nb > 1024) nb = 1024;
     blocks += static_cast<int>(nb);
   }
   m.first[count] = blocks;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
+  if (vec4 && eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi4_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi4_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi4_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
+  else if (eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
   else return fail(HB_ERR_INVALID, "eff_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");

@@ -271,3 +271,43 @@ def test_relu_backward_with_column_sums_and_update_counter():
         a.update()
     warm = 3  # eager warm-up updates run by the graph capture (rlax_rainbow.py: _capture_update_graphs)
     assert a._fl.step.item() == 4 + warm and a.train_step == 4
+
+
+def test_adam_multi_vector_path_equals_scalar_kernel():
+    """hb_noisy_adam_multi (four elements per thread, gradient read from a padded bf16 GEMM output) is bit-identical
+    to hb_noisy_adam (one element per thread, fp32 gradient) on the same data."""
+    import torch
+
+    from hanabi_hip import _capi as K
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rows, cols, ld = 40, 68, 128
+    mk = lambda: torch.randn(rows, cols, device="cuda", generator=g)
+    base = [mk() * 0.1 for _ in range(3)]                                      # w, w_mu, w_sigma
+    noise, grad16 = mk(), torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+    grad16[:, :cols] = (mk() * 0.01).to(torch.bfloat16)
+    moms = [torch.rand(rows, cols, device="cuda", generator=g) * 1e-3 for _ in range(6)]
+    step = torch.tensor(6.0, device="cuda")
+    L, s = K.lib(), K.current_stream()
+    outs = []
+    for vec in (True, False):
+        p = [t.clone() for t in base]
+        m = [t.clone() for t in moms]
+        eff = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+        if vec:
+            tab = (K.HbAdamTensor * 1)()
+            d = tab[0]
+            d.w, d.w_mu, d.w_sigma = (t.data_ptr() for t in p)
+            d.noise, d.grad, d.grad_dtype, d.grad_ld = noise.data_ptr(), grad16.data_ptr(), 1, ld
+            d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma = (t.data_ptr() for t in m)
+            d.eff, d.n, d.cols, d.eff_ld = eff.data_ptr(), rows * cols, cols, ld
+            K.check(L.hb_noisy_adam_multi(tab, 1, K.dptr(step), 1.0, 1, 1e-3, 0.9, 0.999, 3.125e-5, s))
+        else:
+            g32 = grad16[:, :cols].float().contiguous()
+            K.check(L.hb_noisy_adam(K.dptr(p[0]), K.dptr(p[1]), K.dptr(p[2]), K.dptr(noise), K.dptr(g32), K.dptr(m[0]), K.dptr(m[1]),
+                                    K.dptr(m[2]), K.dptr(m[3]), K.dptr(m[4]), K.dptr(m[5]), K.dptr(step), K.dptr(eff), 1,
+                                    rows * cols, cols, ld, 1e-3, 0.9, 0.999, 3.125e-5, s))
+        outs.append(p + m + [eff])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0], base[0])
