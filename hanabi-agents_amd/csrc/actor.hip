@@ -1,0 +1,428 @@
+// actor.hip — the actor's forward pass as two hand-written MFMA kernels for gfx950 (bf16 in, fp32 accumulate).
+//
+// Replaces, for the C51 NoisyMLP with one hidden layer (hanabi_agents/rlax_dqn/rlax_rainbow.py:113-122,141-150 on top
+// of noisy_mlp.py:176-185 with the merged weights W = w + w_mu + w_sigma * eps):
+//
+//   hb_actor_hidden   H = relu(obs @ W1 + b1)              the int8 observation rows are widened to bf16 while they
+//                                                          are staged into LDS: no cast kernel, no bf16 copy of the
+//                                                          observations in HBM
+//   hb_actor_q        q[g, a] = mean_k softmax_k(H @ W2 + b2)[g, a, k] * atoms[k]
+//                                                          the [N, A*K] logits (67 MB at 32 768 games) never reach
+//                                                          HBM: a 256-column tile holds 5 whole actions (5 * 51 =
+//                                                          255), so the C51 expectation is taken from the tile in LDS
+//   hb_policy_select  legal mask, arg-max with uniform tie-breaking, epsilon-greedy (same draws as hb_policy_act)
+//
+// GEMM core (both kernels): 256 x 256 output tile per workgroup of 8 wavefronts (2 x 4; 128 x 64 per wavefront =
+// 32 accumulator tiles of mfma_f32_16x16x32_bf16), K in steps of 64. Both operands are k-contiguous (the weights are
+// kept transposed, hb_actor_pack_weights), staged global -> registers -> LDS with 16-byte accesses, double-buffered
+// (one barrier per K step; the next step's global loads are in flight during the MFMAs). LDS rows are 128 B (64 bf16)
+// with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7, which makes the fragment reads (ds_read_b128, 16 rows x
+// one chunk per 16-lane group) conflict-free. The MFMA operands are swapped (weights as "A", activations as "B") so
+// that a lane ends up with 4 consecutive OUTPUT COLUMNS of one row: the epilogue packs them into one 8-byte LDS write.
+// Roofline: MFMA (bf16 dense 2.5 PFLOP/s). LDS fragment traffic is 0.375 KB per MFMA = 75 % of the MFMA time.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include <cstdint>
+
+#include "../../include/hanabi_hip.h"
+#include "common.hpp"
+#include "env_kernel.hpp"  // philox4x32_10
+
+using hb::fail;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+
+constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+constexpr int ROWB = BK * 2;                      // bytes per LDS row (64 bf16)
+constexpr int STAGE = (BM + BN) * ROWB;           // 64 KB: activations then weights
+constexpr int OUT_LD = 520;                       // bytes per row of the bf16 output tile (2-way conflicts at most)
+constexpr int LDS_BYTES = BM * OUT_LD > 2 * STAGE ? BM * OUT_LD : 2 * STAGE;  // 133 120
+
+struct GemmArgs {
+  const void* x;        // activations: int8 [M, x_ld] (MODE 0) or bf16 [M, x_ld] (MODE 1)
+  long long m;
+  int x_ld;             // row stride in ELEMENTS
+  int k_real;           // valid K of the activations (columns >= k_real read as 0); k_pad = multiple of 64 >= k_real
+  int k_pad;
+  const __hip_bfloat16* wt;  // weights transposed: [n_rows_total][k_pad]
+  const float* bias;         // [n_rows_total]
+  // MODE 0
+  __hip_bfloat16* h;    // [M, h_ld]
+  int h_ld;
+  // MODE 1
+  const float* support;
+  float* q;             // [M, n_actions]
+  int n_actions, n_atoms, group_actions;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+  return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) |
+         (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+}
+// four unsigned bytes of `d` -> four bf16 (exact for 0..255): v_cvt_f32_ubyteN + v_perm_b32
+__device__ __forceinline__ void widen4(uint32_t d, uint32_t& lo, uint32_t& hi) {
+  const float f0 = static_cast<float>(d & 0xFFu), f1 = static_cast<float>((d >> 8) & 0xFFu);
+  const float f2 = static_cast<float>((d >> 16) & 0xFFu), f3 = static_cast<float>(d >> 24);
+  lo = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+  hi = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+}
+
+// C51 expectation of one (row, action): mean_k softmax(x)_k * support_k over KK bf16 logits that start LEAD
+// elements past the 8-byte aligned LDS address p8 (the arithmetic of policy_kernel, policy.hip). The logits are
+// fetched with 8-byte LDS reads (rows are 520 B apart: conflict-free per 32-lane half) instead of KK 2-byte reads,
+// which made this epilogue LDS-issue-bound (22 us of a 60 us kernel).
+template <int KK, int LEAD>
+__device__ __forceinline__ float c51_expectation(const uint2* __restrict__ p8, const float* __restrict__ support) {
+  constexpr int NQ = (LEAD + KK + 3) / 4;
+  uint32_t d[2 * NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const uint2 v = p8[i];
+    d[2 * i] = v.x;
+    d[2 * i + 1] = v.y;
+  }
+  float x[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int h = k + LEAD;
+    x[k] = (h & 1) ? __uint_as_float(d[h >> 1] & 0xFFFF0000u) : __uint_as_float(d[h >> 1] << 16);
+  }
+  float mx = x[0];
+#pragma unroll
+  for (int k = 1; k < KK; ++k) mx = fmaxf(mx, x[k]);
+  float s = 0.f, t = 0.f;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    const float e = __expf(x[k] - mx);
+    s += e;
+    t += e * support[k];
+  }
+  return t / s / static_cast<float>(KK);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k_pad / BK;
+
+  // ---- staging: thread owns 16-byte chunk (r, c) of rows r = (tid >> 3) + 64 i, i = 0..3, for both operands
+  const int sc = tid & 7, sr = tid >> 3;
+  uint4 xr0, xr1, xr2, xr3, wq0, wq1, wq2, wq3;
+#define HB_LOAD_ONE(i, XR, WQ)                                                                                      \
+  {                                                                                                                 \
+    const int r = sr + 64 * (i);                                                                                    \
+    long long row = row0 + r;                                                                                       \
+    if (row >= a.m) row = a.m - 1; /* clamp: rows past the end are computed and dropped */                          \
+    const int k = kt_ * BK + sc * 8;                                                                                \
+    if (MODE == 0) {                                                                                                \
+      const uint8_t* p = static_cast<const uint8_t*>(a.x) + row * a.x_ld + k;                                       \
+      uint32_t d0 = 0, d1 = 0;                                                                                      \
+      if (k + 8 <= a.k_real) {                                                                                      \
+        const u32x2_u v = *reinterpret_cast<const u32x2_u*>(p); /* byte-aligned 8-byte load */                      \
+        d0 = v.x;                                                                                                   \
+        d1 = v.y;                                                                                                   \
+      } else {                                                                                                      \
+        for (int b = 0; b < 8; ++b)                                                                                 \
+          if (k + b < a.k_real) {                                                                                   \
+            if (b < 4) d0 |= static_cast<uint32_t>(p[b]) << (8 * b);                                                \
+            else d1 |= static_cast<uint32_t>(p[b]) << (8 * (b - 4));                                                \
+          }                                                                                                         \
+      }                                                                                                             \
+      XR = make_uint4(d0, d1, 0u, 0u); /* widened when it is written to LDS, after the MFMAs of this step */         \
+    } else {                                                                                                        \
+      XR = *reinterpret_cast<const uint4*>(static_cast<const __hip_bfloat16*>(a.x) + row * a.x_ld + k);            \
+    }                                                                                                               \
+    WQ = *reinterpret_cast<const uint4*>(a.wt + static_cast<long long>(col0 + r) * a.k_pad + k);                    \
+  }
+#define HB_LOAD_STAGE(KT)          \
+  {                                \
+    const int kt_ = (KT);          \
+    HB_LOAD_ONE(0, xr0, wq0)       \
+    HB_LOAD_ONE(1, xr1, wq1)       \
+    HB_LOAD_ONE(2, xr2, wq2)       \
+    HB_LOAD_ONE(3, xr3, wq3)       \
+  }
+#define HB_STORE_ONE(i, XR, WQ)                                                  \
+  {                                                                              \
+    const int r = sr + 64 * (i);                                                 \
+    const int off = r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4);                     \
+    if (MODE == 0) {                                                             \
+      uint32_t e0, e1, e2, e3;                                                   \
+      widen4(XR.x, e0, e1);                                                      \
+      widen4(XR.y, e2, e3);                                                      \
+      *reinterpret_cast<uint4*>(base_ + off) = make_uint4(e0, e1, e2, e3);       \
+    } else {                                                                     \
+      *reinterpret_cast<uint4*>(base_ + off) = XR;                               \
+    }                                                                            \
+    *reinterpret_cast<uint4*>(base_ + BM * ROWB + off) = WQ;                     \
+  }
+#define HB_STORE_STAGE(BUF)                        \
+  {                                                \
+    unsigned char* base_ = lds + (BUF) * STAGE;    \
+    HB_STORE_ONE(0, xr0, wq0)                      \
+    HB_STORE_ONE(1, xr1, wq1)                      \
+    HB_STORE_ONE(2, xr2, wq2)                      \
+    HB_STORE_ONE(3, xr3, wq3)                      \
+  }
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: 16-row tile t of an operand region starting at row base: row = base + 16 t + (lane & 15),
+  // chunk = 4 kk + (lane >> 4); (row >> 1) & 7 == (lane & 15) >> 1 because base and 16 t are multiples of 16
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = BM * ROWB + (wc * 64 + (lane & 15)) * ROWB;
+
+  // Pipeline: while step kt is multiplied out of LDS buffer kt & 1, step kt+1 (loaded into registers one iteration
+  // earlier) is written to the other buffer and the global loads of step kt+2 are issued. One barrier per step: it
+  // both publishes buffer (kt+1) & 1 and retires the reads of buffer kt & 1 before that one is overwritten.
+  HB_LOAD_STAGE(0)
+  HB_STORE_STAGE(0)
+  if (kt_n > 1) HB_LOAD_STAGE(1)
+  __syncthreads();
+  for (int kt = 0; kt < kt_n; ++kt) {
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    if (kt + 1 < kt_n) HB_STORE_STAGE((kt + 1) & 1)
+    if (kt + 2 < kt_n) HB_LOAD_STAGE(kt + 2)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = ((kk * 4 + fq) ^ fsw) << 4;
+      bf16x8 wf[4], xf[8];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[n][m], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[n][m][j] = out[row wr*128 + 16 m + (lane & 15)][col wc*64 + 16 n + 4 (lane >> 4) + j]
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int cl = wc * 64 + n * 16 + fq * 4;
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + col0 + cl);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float v0 = acc[n][m][0] + b.x, v1 = acc[n][m][1] + b.y, v2 = acc[n][m][2] + b.z, v3 = acc[n][m][3] + b.w;
+      if (MODE == 0) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      }
+      const int rl = wr * 128 + m * 16 + (lane & 15);
+      *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+    }
+  }
+#undef HB_LOAD_ONE
+#undef HB_LOAD_STAGE
+#undef HB_STORE_ONE
+#undef HB_STORE_STAGE
+  __syncthreads();
+  if (MODE == 0) {
+    // coalesced copy-out: 32 chunks of 16 bytes per row
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int id = tid + NT * i, r = id >> 5, ch = id & 31;
+      if (row0 + r < a.m)
+        *reinterpret_cast<uint4*>(a.h + (row0 + r) * a.h_ld + col0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + r * OUT_LD + ch * 16);
+    }
+  } else {
+    // C51 expectation per (row, action) from the bf16 logits tile (the arithmetic of policy_kernel, policy.hip)
+    const int K = a.n_atoms;
+    const int first_action = static_cast<int>(blockIdx.y) * a.group_actions;
+    int ga = a.n_actions - first_action;
+    if (ga > a.group_actions) ga = a.group_actions;
+    for (int id = tid; id < BM * ga; id += NT) {
+      const int r = id & (BM - 1), al = id >> 8;
+      const uint16_t* p = reinterpret_cast<const uint16_t*>(lds + r * OUT_LD) + al * K;
+      float qv = 0.f;
+#ifndef HB_ACTOR_SKIP_C51  // (diagnostic builds time the GEMM alone)
+      if (K == 51) {  // the reference's atom count (params.py:18): unrolled, wide LDS reads; `al` is wave-uniform
+        const int start = al * 51 * 2, lead = (start & 7) >> 1;
+        const uint2* p8 = reinterpret_cast<const uint2*>(lds + r * OUT_LD + (start & ~7));
+        if (lead == 0) qv = c51_expectation<51, 0>(p8, a.support);
+        else if (lead == 1) qv = c51_expectation<51, 1>(p8, a.support);
+        else if (lead == 2) qv = c51_expectation<51, 2>(p8, a.support);
+        else qv = c51_expectation<51, 3>(p8, a.support);
+        if (row0 + r < a.m) a.q[(row0 + r) * a.n_actions + first_action + al] = qv;
+        continue;
+      }
+      float mx = -INFINITY;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, __uint_as_float(static_cast<uint32_t>(p[k]) << 16));
+      float s = 0.f, t = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float e = __expf(__uint_as_float(static_cast<uint32_t>(p[k]) << 16) - mx);
+        s += e;
+        t += e * a.support[k];
+      }
+      qv = t / s / static_cast<float>(K);
+#endif
+      if (row0 + r < a.m) a.q[(row0 + r) * a.n_actions + first_action + al] = qv;
+    }
+  }
+}
+
+// weights [K][N] (row stride w_ld) -> transposed [n'][k_pad] with n' = (n / group_cols) * 256 + n % group_cols
+// (group_cols = 0: n' = n); bias -> fp32 at the same n'. 32 x 32 tiles through LDS. Rows / columns that no input
+// maps to are left untouched (the caller zero-initialises the outputs once).
+__global__ __launch_bounds__(256) void pack_weights_kernel(const __hip_bfloat16* __restrict__ w, int k_rows, int n_cols, int w_ld,
+                                                           const __hip_bfloat16* __restrict__ bias, int group_cols,
+                                                           __hip_bfloat16* __restrict__ wt, int k_pad, float* __restrict__ bias_out) {
+  __shared__ __hip_bfloat16 t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, n = n0 + tx;
+    t[i][tx] = (k < k_rows && n < n_cols) ? w[static_cast<long long>(k) * w_ld + n] : __float2bfloat16(0.f);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, k = k0 + tx;
+    if (n < n_cols && k < k_pad) {
+      const int np = group_cols ? (n / group_cols) * 256 + n % group_cols : n;
+      wt[static_cast<long long>(np) * k_pad + k] = t[tx][i];
+    }
+  }
+  if (blockIdx.y == 0 && ty == 0) {
+    const int n = n0 + tx;
+    if (n < n_cols) {
+      const int np = group_cols ? (n / group_cols) * 256 + n % group_cols : n;
+      bias_out[np] = __bfloat162float(bias[n]);
+    }
+  }
+}
+
+// lane per game: the selection rule of policy_kernel (policy.hip) on precomputed q values. A workgroup's 256 games are
+// contiguous in q and legal: fetched with coalesced loads into LDS (row stride A | 1: conflict-free), then scanned
+__global__ __launch_bounds__(256) void policy_select_kernel(const float* __restrict__ q, const int8_t* __restrict__ legal, long long n,
+                                                            int A, float epsilon, unsigned long long seed, unsigned long long draw,
+                                                            long long first_gid, int32_t* __restrict__ actions) {
+  __shared__ float sq[256 * 65];
+  __shared__ int8_t sl[256 * 65];
+  const long long g0 = static_cast<long long>(blockIdx.x) * 256;
+  const int ng = n - g0 < 256 ? static_cast<int>(n - g0) : 256;
+  const int ld = A | 1;
+  for (int e = threadIdx.x; e < ng * A; e += 256) {
+    const int gg = e / A, i = e - gg * A;
+    sq[gg * ld + i] = q[g0 * A + e];
+    sl[gg * ld + i] = legal[g0 * A + e];
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) >= ng) return;
+  const long long g = g0 + threadIdx.x;
+  const float* qr = sq + threadIdx.x * ld;
+  const int8_t* lr = sl + threadIdx.x * ld;
+  float best = -INFINITY;
+  unsigned long long legal_mask = 0;
+  for (int i = 0; i < A; ++i)
+    if (lr[i] != 0) {
+      legal_mask |= 1ull << i;
+      best = fmaxf(best, qr[i]);
+    }
+  unsigned long long ties = 0;
+  for (int i = 0; i < A; ++i)
+    if (((legal_mask >> i) & 1ull) && qr[i] == best) ties |= 1ull << i;
+  const unsigned long long gid = static_cast<unsigned long long>(first_gid + g);
+  uint32_t r[4];
+  hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),
+                    static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+  const float u = static_cast<float>(r[0] >> 8) * (1.0f / 16777216.0f);
+  unsigned long long pool = (u < epsilon) ? legal_mask : ties;
+  if (pool == 0) pool = legal_mask;
+  int pick = 0;
+  const int c = __popcll(pool);
+  if (c > 0) {
+    int k = static_cast<int>(__umulhi(r[1], static_cast<uint32_t>(c)));
+    while (k-- > 0) pool &= pool - 1;
+    pick = __ffsll(static_cast<long long>(pool)) - 1;
+  }
+  actions[g] = pick;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int hb_actor_pack_weights(const void* w_dev, int32_t k_rows, int32_t n_cols, int32_t w_ld, const void* bias_dev, int32_t group_cols,
+                          void* wt_dev, int32_t k_pad, float* bias_out_dev, void* stream) {
+  if (!w_dev || !bias_dev || !wt_dev || !bias_out_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (k_rows < 1 || n_cols < 1 || w_ld < n_cols || k_pad < k_rows || k_pad % 64) return fail(HB_ERR_INVALID, "need w_ld >= n_cols, k_pad >= k_rows and k_pad a multiple of 64");
+  if (group_cols < 0 || group_cols > 256) return fail(HB_ERR_INVALID, "group_cols must be 0..256");
+  const dim3 grid((n_cols + 31) / 32, (k_pad + 31) / 32);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __hip_bfloat16*>(w_dev),
+                     k_rows, n_cols, w_ld, static_cast<const __hip_bfloat16*>(bias_dev), group_cols, static_cast<__hip_bfloat16*>(wt_dev),
+                     k_pad, bias_out_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_actor_hidden(const int8_t* obs_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev, int32_t k_pad, const float* b1_dev,
+                    int32_t hidden, void* h_dev, void* stream) {
+  if (!obs_dev || !w1t_dev || !b1_dev || !h_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_rows <= 0) return HB_OK;
+  if (obs_len < 1 || k_pad < obs_len || k_pad % BK) return fail(HB_ERR_INVALID, "k_pad must be a multiple of 64 and >= obs_len");
+  if (hidden < BN || hidden % BN) return fail(HB_ERR_INVALID, "hidden must be a multiple of 256");
+  if (!aligned16(w1t_dev) || !aligned16(b1_dev) || !aligned16(h_dev)) return fail(HB_ERR_ALIGN, "w1t / b1 / h must be 16-byte aligned");
+  GemmArgs a{};
+  a.x = obs_dev; a.m = n_rows; a.x_ld = obs_len; a.k_real = obs_len; a.k_pad = k_pad;
+  a.wt = static_cast<const __hip_bfloat16*>(w1t_dev); a.bias = b1_dev;
+  a.h = static_cast<__hip_bfloat16*>(h_dev); a.h_ld = hidden;
+  const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(hidden / BN));
+  hipLaunchKernelGGL((actor_gemm_kernel<0>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev, const float* support_dev,
+               int32_t n_actions, int32_t n_atoms, float* q_dev, void* stream) {
+  if (!h_dev || !w2t_dev || !b2_dev || !support_dev || !q_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_rows <= 0) return HB_OK;
+  if (hidden < BK || hidden % BK) return fail(HB_ERR_INVALID, "hidden must be a multiple of 64");
+  if (n_actions < 1 || n_atoms < 2 || n_atoms > 256) return fail(HB_ERR_INVALID, "need n_actions >= 1 and 2 <= n_atoms <= 256");
+  if (!aligned16(h_dev) || !aligned16(w2t_dev) || !aligned16(b2_dev)) return fail(HB_ERR_ALIGN, "h / w2t / b2 must be 16-byte aligned");
+  GemmArgs a{};
+  a.x = h_dev; a.m = n_rows; a.x_ld = hidden; a.k_real = hidden; a.k_pad = hidden;
+  a.wt = static_cast<const __hip_bfloat16*>(w2t_dev); a.bias = b2_dev;
+  a.support = support_dev; a.q = q_dev; a.n_actions = n_actions; a.n_atoms = n_atoms;
+  a.group_actions = 256 / n_atoms;
+  const int groups = (n_actions + a.group_actions - 1) / a.group_actions;
+  const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(groups));
+  hipLaunchKernelGGL((actor_gemm_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_games, int32_t n_actions, float epsilon, uint64_t seed,
+                     uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream) {
+  if (!q_dev || !legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
+  if (n_games <= 0) return HB_OK;
+  hipLaunchKernelGGL(policy_select_kernel, dim3(static_cast<unsigned>((n_games + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), q_dev, legal_dev, static_cast<long long>(n_games), n_actions, epsilon,
+                     static_cast<unsigned long long>(seed), static_cast<unsigned long long>(draw), static_cast<long long>(first_game_id),
+                     actions_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+}  // extern "C"
