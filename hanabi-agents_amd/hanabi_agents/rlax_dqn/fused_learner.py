@@ -84,6 +84,12 @@ class FusedLearner:
         # backward GEMMs and the bias gradients from the column-sum outputs: no pack / convert launches. With data
         # parallelism the gradients are first packed into the flat fp32 all-reduce bucket above.
         self.direct = agent._dp_world() == 1
+        # the actor's forward on the hand-written MFMA kernels (csrc/actor.hip) reads transposed copies of eff
+        from hanabi_hip.ops import ActorMFMA
+
+        self.actor = None
+        if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd) and getattr(agent, "use_mfma_actor", True):
+            self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev)
         self._gw2_out = torch.zeros(H, self.Np, dtype=self.cd, device=dev)
         self._gw1_out = torch.zeros(self.Kp, H, dtype=self.cd, device=dev)
         self.refresh_effective()
@@ -99,6 +105,12 @@ class FusedLearner:
     def refresh_effective(self):
         for (w_e, b_e), l in zip(self.eff, self.layers):
             self._store(w_e, b_e, *l.effective())
+        self.pack_actor()
+
+    def pack_actor(self):
+        if self.actor is not None:
+            (w1, b1), (w2, b2) = self.eff
+            self.actor.pack(w1, b1, w2, b2)
 
     @torch.no_grad()
     def refresh_target(self):
@@ -170,6 +182,7 @@ class FusedLearner:
         # self.step was advanced by this update's loss kernel (part1): it already is this step's number
         K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
                                             float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
+        self.pack_actor()
 
     def loss(self):
         return torch.mean(self.td * self.w_is)

@@ -181,6 +181,7 @@ class DQNAgent:
         self._disc = params.discount  # scalar gamma, or the [B] tensor gamma^m of the current n-step batch
         self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
         self.use_fused_learner = use_fused_learner
+        self.use_mfma_actor = True   # csrc/actor.hip when the FusedLearner can feed it; False = cast + library GEMMs + hb_policy_act
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
 
@@ -233,6 +234,12 @@ class DQNAgent:
             self.online.resample()
             self._eff_cache = None
         eff = self._effective_weights()
+        fl = self._fl
+        if fl is not None and fl.actor is not None and obs.dtype == torch.int8 and self.use_mfma_actor:
+            # hand-written MFMA path: int8 observations in, actions out; no bf16 copy of the observations and no logits in HBM
+            self._draws += 1
+            return fl.actor.act(obs.contiguous(), legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
+                                self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
         cd = eff[0][0].dtype
         kp = eff[0][0].shape[0]                     # first-layer K, possibly padded (FusedLearner keeps padded operands)
         if obs.dtype == torch.int8 and cd != torch.float32:
@@ -608,6 +615,7 @@ class DQNAgent:
                     dst.copy_(src)
                 for dst, src in zip([t for pair in fl.trg for t in pair], f["trg"]):
                     dst.copy_(src)
+                fl.pack_actor()
             else:
                 self.optimizer.load_state_dict(sd["optimizer"])
                 self._trg_cache = None

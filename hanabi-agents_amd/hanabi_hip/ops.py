@@ -1,4 +1,4 @@
-"""Thin wrappers over the fused actor-tail and replay-insert kernels (hb_policy_act, hb_replay_insert)."""
+"""Thin wrappers over the actor and replay-insert kernels (hb_policy_act, hb_actor_*, hb_replay_insert)."""
 import torch
 
 from . import _capi as K
@@ -42,3 +42,50 @@ def replay_insert(last_obs, obs, legal, actions, rewards, step_types, ring, star
                                      K.dptr(ring._act_tm1_buf), K.dptr(ring._lms_t_buf), K.dptr(ring._rew_t_buf),
                                      K.dptr(ring._terminal_t_buf), n, obs_len, legal.shape[1], ring.capacity, int(start),
                                      K.current_stream()))
+
+
+class ActorMFMA:
+    """The actor's forward pass on the hand-written MFMA kernels (csrc/actor.hip): packed (transposed) copies of
+    the effective weights plus the scratch buffers; `pack` after every weight change, `act` per step."""
+
+    def __init__(self, obs_len, hidden, n_actions, n_atoms, k_pad, device):
+        assert k_pad % 64 == 0 and k_pad >= obs_len and hidden % 256 == 0 and 2 <= n_atoms <= 256
+        self.obs_len, self.hidden, self.n_actions, self.n_atoms, self.k_pad = obs_len, hidden, n_actions, n_atoms, k_pad
+        self.group_actions = 256 // n_atoms
+        groups = -(-n_actions // self.group_actions)
+        bf = dict(dtype=torch.bfloat16, device=device)
+        self.w1t = torch.zeros(hidden, k_pad, **bf)
+        self.b1 = torch.zeros(hidden, dtype=torch.float32, device=device)
+        self.w2t = torch.zeros(groups * 256, hidden, **bf)
+        self.b2 = torch.zeros(groups * 256, dtype=torch.float32, device=device)
+        self.h = self.q = self.actions = None
+
+    @staticmethod
+    def supports(obs_len, hidden, n_atoms, k_pad, dtype):
+        return dtype == torch.bfloat16 and k_pad % 64 == 0 and hidden % 256 == 0 and 2 <= n_atoms <= 256
+
+    def pack(self, w1, b1, w2, b2):
+        """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K]."""
+        L, s = K.lib(), K.current_stream()
+        ak = self.n_actions * self.n_atoms
+        K.check(L.hb_actor_pack_weights(K.dptr(w1), self.obs_len, self.hidden, w1.stride(0), K.dptr(b1), 0, K.dptr(self.w1t),
+                                        self.k_pad, K.dptr(self.b1), s))
+        K.check(L.hb_actor_pack_weights(K.dptr(w2), self.hidden, ak, w2.stride(0), K.dptr(b2), self.group_actions * self.n_atoms,
+                                        K.dptr(self.w2t), self.hidden, K.dptr(self.b2), s))
+
+    def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0):
+        n = obs.shape[0]
+        assert obs.dtype == torch.int8 and obs.is_contiguous() and obs.shape[1] == self.obs_len
+        assert legal.dtype == torch.int8 and legal.is_contiguous() and legal.shape == (n, self.n_actions)
+        if self.h is None or self.h.shape[0] != n:
+            self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
+            self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
+        actions = torch.empty(n, dtype=torch.int32, device=obs.device)
+        L, s = K.lib(), K.current_stream()
+        K.check(L.hb_actor_hidden(K.dptr(obs), n, self.obs_len, K.dptr(self.w1t), self.k_pad, K.dptr(self.b1), self.hidden,
+                                  K.dptr(self.h), s))
+        K.check(L.hb_actor_q(K.dptr(self.h), n, self.hidden, K.dptr(self.w2t), K.dptr(self.b2), K.dptr(support), self.n_actions,
+                             self.n_atoms, K.dptr(self.q), s))
+        K.check(L.hb_policy_select(K.dptr(self.q), K.dptr(legal), n, self.n_actions, float(epsilon), int(seed), int(draw),
+                                   int(first_game_id), K.dptr(actions), s))
+        return actions
