@@ -94,9 +94,11 @@ def test_other_configs_run_end_to_end(game, players, kwargs):
     assert int(env.current_player()[0]) == (6 * players) % players and bool((env.current_player() == env.current_player()[0]).all())
 
 
-def test_learner_stream_gives_identical_training():
+@pytest.mark.parametrize("dtype,graphs", [("float32", False), ("bfloat16", True)])
+def test_learner_stream_gives_identical_training(dtype, graphs):
     """Running the updates on the second stream keeps every dependency of the sequential order: two sessions
-    with the same seeds end with identical weights and replay contents."""
+    with the same seeds end with identical weights and replay contents. The bfloat16 case acts through the MFMA
+    actor kernels, whose packed weights are rewritten by the learner stream inside its captured graph."""
     import torch
 
     import hanabi_hip
@@ -108,12 +110,14 @@ def test_learner_stream_gives_identical_training():
         torch.cuda.manual_seed(0)
         flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
         env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=256, seed=5)
-        params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=4096, mask_terminal=True, target_update_period=7)
+        params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=4096, mask_terminal=True, target_update_period=7,
+                                   compute_dtype=dtype)
         agents = [DQNAgent(ObservationSpec((256, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda",
-                           use_graphs=False) for s in (1, 2)]
+                           use_graphs=graphs) for s in (1, 2)]
         sess = SelfPlaySession(env, agents, learner_stream=lstream)
         sess.run(40)
         torch.cuda.synchronize()
+        assert (agents[0]._fl.actor is not None) == (dtype == "bfloat16")
         return [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]) for a in agents], env.export_state()
 
     (w_a, st_a), (w_b, st_b) = run(False), run(True)
