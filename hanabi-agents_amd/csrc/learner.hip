@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
                                                   const float* __restrict__ beta_dev, const float* __restrict__ disc, int mask_terminal,
                                                   const float* __restrict__ support, int B, int A, int K, int rs,
                                                   float* __restrict__ td_out, float* __restrict__ w_out,
-                                                  T* __restrict__ dlogits, float* __restrict__ counter) {
+                                                  T* __restrict__ dlogits, float* __restrict__ counter,
+                                                  const T* __restrict__ bias_on, const T* __restrict__ bias_t) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wave;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   const float w_b = powf(static_cast<float>(1.0 / prios[b]), beta) / wmax;
   // ---- double-Q selector: q_sel[a] = mean(softmax(online(obs_t))[a] * z) (no legal mask, as the reference)
   const T* row_sel = logits_on + static_cast<long long>(B + b) * rs;  // rows are rs >= A*K elements apart
-  for (int e = lane; e < AK; e += 64) sel[e] = ld<T>(row_sel, e);
+  // (bias_on / bias_t: output-layer biases not yet added by the caller's GEMM, e.g. a batched GEMM without epilogue)
+  for (int e = lane; e < AK; e += 64) sel[e] = ld<T>(row_sel, e) + (bias_on ? ld<T>(bias_on, e) : 0.f);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -146,7 +148,9 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   const int a_star = __ffsll(static_cast<long long>(hit)) - 1;  // lowest index among ties, like argmax
   // ---- target distribution p = softmax(target(obs_t)[a*]) and its projection onto the support
   const bool atom = lane < K;
-  const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * rs + a_star * K + lane) : -INFINITY;
+  const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * rs + a_star * K + lane) +
+                              (bias_t ? ld<T>(bias_t, a_star * K + lane) : 0.f)
+                        : -INFINITY;
   const float mt = wave_max(lt);
   const float et = atom ? __expf(lt - mt) : 0.f;
   const float p = et / wave_sum(et);
@@ -166,7 +170,9 @@ __global__ __launch_bounds__(256) void c51_kernel(const T* __restrict__ logits_o
   if (!atom) target = 0.f;
   // ---- cross-entropy against log_softmax(online(obs_tm1)[a_tm1]) and its gradient
   const int a_tm1 = act[b];
-  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * rs + a_tm1 * K + lane) : -INFINITY;
+  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * rs + a_tm1 * K + lane) +
+                              (bias_on ? ld<T>(bias_on, a_tm1 * K + lane) : 0.f)
+                        : -INFINITY;
   const float m1 = wave_max(l1);
   const float e1 = atom ? __expf(l1 - m1) : 0.f;
   const float s1 = wave_sum(e1);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, i
 // colsum_kernel.
 template <typename T>
 __global__ __launch_bounds__(1024) void relu_bwd_colsum_kernel(T* __restrict__ dy, const T* __restrict__ act, int rows, int cols,
-                                                               float* __restrict__ out) {
+                                                               int act_ld, float* __restrict__ out) {
   __shared__ float part[16][64];
   const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, rg = threadIdx.x >> 6;
   float s = 0.f;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(1024) void relu_bwd_colsum_kernel(T* __restrict__ d
 #pragma unroll 16
     for (int i = rg; i < rows; i += 16) {
       const long long k = static_cast<long long>(i) * cols + c;
-      const float g = ld<T>(act, k) > 0.f ? ld<T>(dy, k) : 0.f;
+      const float g = ld<T>(act, static_cast<long long>(i) * act_ld + c) > 0.f ? ld<T>(dy, k) : 0.f;
       st<T>(dy, k, g);
       s += g;
     }
@@ -425,7 +431,7 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev, float* update_counter_dev,
-                     void* stream) {
+                     const void* bias_online_dev, const void* bias_target_dev, void* stream) {
   if (!logits_online_dev || !logits_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev || !disc_dev ||
       !support_dev || !td_dev || !w_dev || !dlogits_dev)
     return fail(HB_ERR_INVALID, "null argument");
@@ -440,7 +446,7 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
   hipLaunchKernelGGL((c51_kernel<T>), grid, block, lds, s, static_cast<const T*>(logits_online_dev),                    \
                      static_cast<const T*>(logits_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, disc_dev, \
                      mask_terminal, support_dev, B, n_actions, n_atoms, row_stride, td_dev, w_dev, static_cast<T*>(dlogits_dev),       \
-                     update_counter_dev)
+                     update_counter_dev, static_cast<const T*>(bias_online_dev), static_cast<const T*>(bias_target_dev))
   if (dtype == 0) HB_C51(float);
   else if (dtype == 1) HB_C51(__hip_bfloat16);
   else if (dtype == 2) HB_C51(__half);
@@ -484,16 +490,19 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
   return HB_OK;
 }
 
-int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev,
-                       void* stream) {
+int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int64_t act_ld, int32_t dtype, int64_t rows, int64_t cols,
+                       float* out_dev, void* stream) {
   if (!dy_dev || !act_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
   if (rows <= 0 || cols <= 0) return HB_OK;
+  if (act_ld == 0) act_ld = cols;
+  if (act_ld < cols) return fail(HB_ERR_INVALID, "act_ld must be 0 or >= cols");
+  const int al = static_cast<int>(act_ld);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>((cols + 63) / 64)), block(1024);
   const int r = static_cast<int>(rows), c = static_cast<int>(cols);
-  if (dtype == 0) hipLaunchKernelGGL((relu_bwd_colsum_kernel<float>), grid, block, 0, s, static_cast<float*>(dy_dev), static_cast<const float*>(act_dev), r, c, out_dev);
-  else if (dtype == 1) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__hip_bfloat16>), grid, block, 0, s, static_cast<__hip_bfloat16*>(dy_dev), static_cast<const __hip_bfloat16*>(act_dev), r, c, out_dev);
-  else if (dtype == 2) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__half>), grid, block, 0, s, static_cast<__half*>(dy_dev), static_cast<const __half*>(act_dev), r, c, out_dev);
+  if (dtype == 0) hipLaunchKernelGGL((relu_bwd_colsum_kernel<float>), grid, block, 0, s, static_cast<float*>(dy_dev), static_cast<const float*>(act_dev), r, c, al, out_dev);
+  else if (dtype == 1) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__hip_bfloat16>), grid, block, 0, s, static_cast<__hip_bfloat16*>(dy_dev), static_cast<const __hip_bfloat16*>(act_dev), r, c, al, out_dev);
+  else if (dtype == 2) hipLaunchKernelGGL((relu_bwd_colsum_kernel<__half>), grid, block, 0, s, static_cast<__half*>(dy_dev), static_cast<const __half*>(act_dev), r, c, al, out_dev);
   else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
   return HB_OK;

@@ -4,8 +4,9 @@ Same arithmetic as `DQNLearning.loss` + `torch.optim.Adam` on the NoisyMLP (the 
 path in rlax_rainbow.py stays as the fp32 reference and is what runs on the CPU), arranged as
 
     PER sample (hb_per_sample)  ->  gather into the GEMM operand (hb_replay_gather)
-    ->  online pass on 2B rows + target pass on B rows: torch.addmm on MFMA, effective weights
-        W = w + w_mu + w_sigma*eps already materialised in the GEMM dtype
+    ->  online and target passes together: one GEMM per layer (layer 1 on the concatenated [W1 | W1_target], layer 2
+        as a batched GEMM over the two networks), effective weights W = w + w_mu + w_sigma*eps already materialised in
+        the GEMM dtype
     ->  hb_c51_loss_grad: IS weights, double-Q selection, projection, cross-entropy, dLoss/dlogits
     ->  backward by hand: dW2 = H^T dlogits, dH = dlogits W2^T masked by ReLU, dW1 = X^T dH,
         bias grads by column sums
@@ -47,9 +48,16 @@ class FusedLearner:
         pad = (lambda v, m: (v + m - 1) // m * m) if self.cd != torch.float32 else (lambda v, m: v)
         self.Kp = pad(self.L, 64)           # first-layer K
         self.Np = pad(AK, 64)               # second-layer N (logits row stride)
-        self.eff = [(torch.zeros(self.Kp, H, dtype=self.cd, device=dev), torch.zeros(H, dtype=self.cd, device=dev)),
-                    (torch.zeros(H, self.Np, dtype=self.cd, device=dev), torch.zeros(self.Np, dtype=self.cd, device=dev))]
-        self.trg = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in self.eff]
+        # Online and target operands live side by side so that ONE GEMM per layer serves both networks:
+        #   layer 1: X [2B, Kp] @ [W1 | W1_target] [Kp, 2H]           (the target half of rows 0..B-1 is unused work)
+        #   layer 2: batched GEMM over {online, target}: [2, 2B, H] @ [2, H, Np]; the biases are added by the loss kernel
+        self.w1cat = torch.zeros(self.Kp, 2 * H, dtype=self.cd, device=dev)
+        self.b1cat = torch.zeros(2 * H, dtype=self.cd, device=dev)
+        self.w2st = torch.zeros(2, H, self.Np, dtype=self.cd, device=dev)
+        self.b2st = torch.zeros(2, self.Np, dtype=self.cd, device=dev)
+        self.eff = [(self.w1cat[:, :H], self.b1cat[:H]), (self.w2st[0], self.b2st[0])]
+        self.trg = [(self.w1cat[:, H:], self.b1cat[H:]), (self.w2st[1], self.b2st[1])]
+        self.H = H
         # flat gradient buffer [dW1 | db1 | dW2 | db2] (fp32), one all-reduce bucket
         sizes = [layers[0].w.numel(), H, layers[1].w.numel(), AK]
         self.flat_grad = torch.zeros(sum(sizes), **f32)
@@ -88,6 +96,7 @@ class FusedLearner:
         from hanabi_hip.ops import ActorMFMA
 
         self.actor = None
+        self.actor_stale = True
         if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd) and getattr(agent, "use_mfma_actor", True):
             self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev)
         self._gw2_out = torch.zeros(H, self.Np, dtype=self.cd, device=dev)
@@ -105,12 +114,16 @@ class FusedLearner:
     def refresh_effective(self):
         for (w_e, b_e), l in zip(self.eff, self.layers):
             self._store(w_e, b_e, *l.effective())
-        self.pack_actor()
+        self.actor_stale = True
 
     def pack_actor(self):
-        if self.actor is not None:
+        """Refresh the actor's transposed weight copies if the effective weights changed since the last call. Runs on
+        the ACTING stream just before the actor kernels (the update that wrote `eff` has been waited for by then), so the
+        two small launches stay off the learner chain, which is the critical path of a step."""
+        if self.actor is not None and self.actor_stale:
             (w1, b1), (w2, b2) = self.eff
             self.actor.pack(w1, b1, w2, b2)
+            self.actor_stale = False
 
     @torch.no_grad()
     def refresh_target(self):
@@ -130,20 +143,21 @@ class FusedLearner:
                                    K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(self.disc), int(a.params.n_step), float(a.params.discount),
                                    buf.capacity, int(buf.rows_per_insert or 1), K.dptr(buf._size_wp), s))
-        (w1, b1), (w2, b2) = self.eff
-        h = torch._addmm_activation(b1, self.x, w1, use_gelu=False)  # bias + ReLU in the GEMM epilogue, [2B, H]
-        logits_on = torch.addmm(b2, h, w2)                          # [2B, A*K]
-        (tw1, tb1), (tw2, tb2) = self.trg
-        logits_t = torch.addmm(tb2, torch._addmm_activation(tb1, self.x[B:], tw1, use_gelu=False), tw2)
+        H = self.H
+        w2 = self.eff[1][0]
+        hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
+        logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy
+        logits_on, logits_t = logits[0], logits[1, B:]                                   # online on all 2B rows, target on obs_t
         K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
                                    1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
-                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step), s))
-        hb, xb, dl = h[:B], self.x[:B], self.dlogits
+                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step),
+                                   K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
+        hb, xb, dl = hcat[:B, :H], self.x[:B], self.dlogits
         torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
         K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
         dh = torch.mm(dl, w2.t())                                      # masked by the ReLU in place, with its column sums
-        K.check(L.hb_relu_bwd_colsum(K.dptr(dh), K.dptr(hb), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
+        K.check(L.hb_relu_bwd_colsum(K.dptr(dh), K.dptr(hb), hb.stride(0), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         torch.mm(xb.t(), dh, out=self._gw1_out)                       # [Kp, H]; the padding rows are never read
         if not self.direct:  # pack the all-reduce bucket (fp32, unpadded)
             self.g_w2.copy_(self._gw2_out[:, :self.AK])
@@ -172,7 +186,8 @@ class FusedLearner:
                     d.m_w, d.v_w = st[0][0].data_ptr(), st[0][1].data_ptr()
                     d.m_mu, d.v_mu = st[1][0].data_ptr(), st[1][1].data_ptr()
                     d.m_sigma, d.v_sigma = st[2][0].data_ptr(), st[2][1].data_ptr()
-                    d.eff, d.n, d.cols, d.eff_ld = eff.data_ptr(), ps[0].numel(), ps[0].shape[-1], eff.shape[-1]
+                    d.eff, d.n, d.cols = eff.data_ptr(), ps[0].numel(), ps[0].shape[-1]
+                    d.eff_ld = eff.stride(0) if eff.dim() == 2 else eff.shape[-1]   # eff may be a column block of a wider buffer
                     k += 1
             self._adam_tab = tab
         return self._adam_tab
@@ -182,7 +197,6 @@ class FusedLearner:
         # self.step was advanced by this update's loss kernel (part1): it already is this step's number
         K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
                                             float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
-        self.pack_actor()
 
     def loss(self):
         return torch.mean(self.td * self.w_is)

@@ -237,6 +237,7 @@ class DQNAgent:
         fl = self._fl
         if fl is not None and fl.actor is not None and obs.dtype == torch.int8 and self.use_mfma_actor:
             # hand-written MFMA path: int8 observations in, actions out; no bf16 copy of the observations and no logits in HBM
+            fl.pack_actor()
             self._draws += 1
             return fl.actor.act(obs.contiguous(), legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
                                 self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
@@ -374,6 +375,8 @@ class DQNAgent:
         else:
             self._update_part2(*part2_args)
         self._eff_cache = None
+        if self._fl is not None:
+            self._fl.actor_stale = True  # Adam rewrote the effective weights: repack before the next act
         if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
             self._sync_target()
         self.train_step += 1
@@ -615,7 +618,7 @@ class DQNAgent:
                     dst.copy_(src)
                 for dst, src in zip([t for pair in fl.trg for t in pair], f["trg"]):
                     dst.copy_(src)
-                fl.pack_actor()
+                fl.actor_stale = True
             else:
                 self.optimizer.load_state_dict(sd["optimizer"])
                 self._trg_cache = None

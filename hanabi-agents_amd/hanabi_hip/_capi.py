@@ -108,7 +108,7 @@ SIGNATURES = {
     "hb_obs_cast": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "hb_policy_act": (C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _I32, C.c_float, _U64, _U64, _I64, _P, _P, _P]),
     "hb_replay_gather": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
-    "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "hb_noisy_adam": (C.c_int, [_P] * 11 + [_P, _P, _I32, _I64, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_noisy_adam_multi": (C.c_int, [C.POINTER(HbAdamTensor), _I32, _P, C.c_float, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
@@ -116,7 +116,7 @@ SIGNATURES = {
     "hb_actor_hidden": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
     "hb_actor_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P]),
     "hb_policy_select": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _U64, _U64, _I64, _P, _P]),
-    "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I32, _I64, _I64, _P, _P]),
+    "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }
 

@@ -321,12 +321,14 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
  *   disc_dev [B]: per-sample discount (gamma for 1-step, gamma^m for n-step transitions).
  *   mask_terminal != 0 multiplies the discount by (1 - term) (off = the reference, App. C-5).
  *   update_counter_dev: NULL, or a device float that this launch increments by one: a per-update counter for the
- *   caller (the optimizer's step number, see hb_noisy_adam_multi's step_offset) without a launch of its own. */
+ *   caller (the optimizer's step number, see hb_noisy_adam_multi's step_offset) without a launch of its own.
+ *   bias_online_dev / bias_target_dev: NULL, or the output layers' biases [A*K] (same dtype as the logits) when the
+ *   caller's GEMM has not added them (one batched GEMM for both networks has no bias epilogue).               */
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
                      const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
                      const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev,
-                     float* update_counter_dev, void* stream);
+                     float* update_counter_dev, const void* bias_online_dev, const void* bias_target_dev, void* stream);
 
 /* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:
  * the column sums of dLoss/dlogits and of dLoss/dhidden). x_dev [rows, cols] contiguous.        */
@@ -362,8 +364,8 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors /* host array of device po
 /* ReLU backward fused with the bias gradient (the `jax.grad` of relu + the bias add, rlax_rainbow.py:203-206 through
  * noisy_mlp.py:176-185): dy_dev [rows, cols] is masked in place where act_dev (the post-activation) is <= 0, and
  * out_dev[j] = sum over rows of the masked values (fp32, fixed order).                                          */
-int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int32_t dtype, int64_t rows, int64_t cols, float* out_dev,
-                       void* stream);
+int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int64_t act_ld /* row stride of act_dev, 0 = cols */, int32_t dtype,
+                       int64_t rows, int64_t cols, float* out_dev, void* stream);
 
 /* ---- actor forward on MFMA (csrc/actor.hip): rlax_rainbow.py:113-122,141-150 over noisy_mlp.py:176-185 ------------
  * For the C51 network with ONE hidden layer and bf16 effective weights W = w + w_mu + w_sigma * eps:

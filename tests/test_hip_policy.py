@@ -265,7 +265,7 @@ def test_relu_backward_with_column_sums_and_update_counter():
         want = torch.ops.aten.threshold_backward(dy, act, 0.0)
         out = torch.empty(512, device="cuda")
         got = dy.clone()
-        K.check(K.lib().hb_relu_bwd_colsum(K.dptr(got), K.dptr(act), code, 256, 512, K.dptr(out), K.current_stream()))
+        K.check(K.lib().hb_relu_bwd_colsum(K.dptr(got), K.dptr(act), 0, code, 256, 512, K.dptr(out), K.current_stream()))
         assert torch.equal(got, want)
         ref = torch.empty(512, device="cuda")
         K.check(K.lib().hb_colsum(K.dptr(want), code, 256, 512, K.dptr(ref), K.current_stream()))
