@@ -327,10 +327,21 @@ def qnet_roofline(agent, env, args):
     learn_s = a.elapsed_time(b) / 1e3 / reps
     peak = MFMA_PEAK_TFLOPS[args.compute_dtype]
     actor_tf = fwd_flop * n / actor_s / 1e12
+    # what the actor kernels execute: merged weights (one GEMM per layer), K padded to a multiple of 64, output columns in
+    # 256-column groups of whole actions (csrc/actor.hip)
+    fl = getattr(agent, "_fl", None)
+    mfma_actor = fl is not None and fl.actor is not None and agent.use_mfma_actor
+    kp = -(-env.obs_len // 64) * 64
+    ncols = fl.actor.w2t.shape[0] if mfma_actor else -(-env.num_actions * agent.params.n_atoms // 64) * 64
+    exec_flop = 2.0 * (kp * hidden + hidden * ncols)
+    exec_tf = exec_flop * n / actor_s / 1e12
     learn_tf = 5.0 * 256 * fwd_flop / learn_s / 1e12
     return {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "dtype": args.compute_dtype,
             "actor_forward": {"rows": n, "algorithmic_gflop": fwd_flop * n / 1e9, "ms": actor_s * 1e3, "achieved": actor_tf,
-                              "frac": actor_tf / peak},
+                              "frac": actor_tf / peak, "executed_gflop": exec_flop * n / 1e9, "executed_achieved": exec_tf,
+                              "executed_frac": exec_tf / peak,
+                              "kernels": ("hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
+                                          if mfma_actor else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act")},
             "learner_update": {"batch": 256, "algorithmic_gflop": 5.0 * 256 * fwd_flop / 1e9, "ms": learn_s * 1e3,
                                "achieved": learn_tf, "frac": learn_tf / peak, "grad_steps_per_sec_alone": 1.0 / learn_s}}
 
