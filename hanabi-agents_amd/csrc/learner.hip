@@ -269,6 +269,12 @@ __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, flo
   // torch.optim.Adam / optix.adam: eps outside the sqrt
   return __fsub_rn(p, __fdiv_rn(__fmul_rn(lr / bc1, m), __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), eps)));
 }
+// The step Adam takes for moments (m, v): p_new = p - adam_step(...). w and w_mu of a NoisyLinear always see the same
+// gradient, so their moments are equal for ever; a caller may pass the SAME moment arrays for both (m_mu == m_w,
+// v_mu == v_w) and the kernels then apply w's step to w_mu without touching the moments a second time.
+__device__ __forceinline__ float adam_step(float m, float v, float bc1, float bc2s, float lr, float eps) {
+  return __fdiv_rn(__fmul_rn(lr / bc1, m), __fadd_rn(__fdiv_rn(sqrtf(v), bc2s), eps));
+}
 __device__ __forceinline__ float merged(float w, float mu, float sg, float nz) {  // W = w + w_mu + w_sigma * noise
   return __fadd_rn(__fadd_rn(w, mu), __fmul_rn(sg, nz));
 }
@@ -286,9 +292,15 @@ __global__ __launch_bounds__(256) void noisy_adam_kernel(const AdamArgs a) {
     m = a.m_w[i]; v = a.v_w[i];
     const float w = adam1(a.w[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_w[i] = m; a.v_w[i] = v; a.w[i] = w;
-    m = a.m_mu[i]; v = a.v_mu[i];
-    const float mu = adam1(a.w_mu[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
-    a.m_mu[i] = m; a.v_mu[i] = v; a.w_mu[i] = mu;
+    float mu;
+    if (a.m_mu == a.m_w) {  // shared moments: (m, v) are w's, already advanced
+      mu = __fsub_rn(a.w_mu[i], adam_step(m, v, bc1, bc2s, a.lr, a.eps));
+    } else {
+      m = a.m_mu[i]; v = a.v_mu[i];
+      mu = adam1(a.w_mu[i], g, m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+      a.m_mu[i] = m; a.v_mu[i] = v;
+    }
+    a.w_mu[i] = mu;
     m = a.m_sg[i]; v = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], __fmul_rn(g, nz), m, v, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = m; a.v_sg[i] = v; a.w_sigma[i] = sg;
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256) void noisy_adam_multi4_kernel(const AdamMulti 
     load_grad4<T>(a.grad, a.grad_dtype, static_cast<long long>(row) * a.grad_ld + col, g);
     const float4 nz4 = *reinterpret_cast<const float4*>(a.noise + i);
     const float nz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
-    float res[3][4];
+    float res[3][4], lm[4], lv[4];
     auto one = [&](float* p, float* mp, float* vp, int which) {
       float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(mp + i), vv = *reinterpret_cast<float4*>(vp + i);
       float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -346,13 +358,25 @@ __global__ __launch_bounds__(256) void noisy_adam_multi4_kernel(const AdamMulti 
       for (int k = 0; k < 4; ++k) {
         pa[k] = adam1(pa[k], which == 2 ? __fmul_rn(g[k], nz[k]) : g[k], ma[k], va[k], a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
         res[which][k] = pa[k];
+        lm[k] = ma[k];
+        lv[k] = va[k];
       }
       *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
       *reinterpret_cast<float4*>(mp + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *reinterpret_cast<float4*>(vp + i) = make_float4(va[0], va[1], va[2], va[3]);
     };
     one(a.w, a.m_w, a.v_w, 0);
-    one(a.w_mu, a.m_mu, a.v_mu, 1);
+    if (a.m_mu == a.m_w) {  // shared moments: apply w's step to w_mu
+      float4 pv = *reinterpret_cast<float4*>(a.w_mu + i);
+      pv.x = __fsub_rn(pv.x, adam_step(lm[0], lv[0], bc1, bc2s, a.lr, a.eps));
+      pv.y = __fsub_rn(pv.y, adam_step(lm[1], lv[1], bc1, bc2s, a.lr, a.eps));
+      pv.z = __fsub_rn(pv.z, adam_step(lm[2], lv[2], bc1, bc2s, a.lr, a.eps));
+      pv.w = __fsub_rn(pv.w, adam_step(lm[3], lv[3], bc1, bc2s, a.lr, a.eps));
+      *reinterpret_cast<float4*>(a.w_mu + i) = pv;
+      res[1][0] = pv.x; res[1][1] = pv.y; res[1][2] = pv.z; res[1][3] = pv.w;
+    } else {
+      one(a.w_mu, a.m_mu, a.v_mu, 1);
+    }
     one(a.w_sigma, a.m_sg, a.v_sg, 2);
     const long long e = static_cast<long long>(row) * a.eff_ld + col;
 #pragma unroll
@@ -377,9 +401,15 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
     mm = a.m_w[i]; vv = a.v_w[i];
     const float w = adam1(a.w[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_w[i] = mm; a.v_w[i] = vv; a.w[i] = w;
-    mm = a.m_mu[i]; vv = a.v_mu[i];
-    const float mu = adam1(a.w_mu[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
-    a.m_mu[i] = mm; a.v_mu[i] = vv; a.w_mu[i] = mu;
+    float mu;
+    if (a.m_mu == a.m_w) {
+      mu = __fsub_rn(a.w_mu[i], adam_step(mm, vv, bc1, bc2s, a.lr, a.eps));
+    } else {
+      mm = a.m_mu[i]; vv = a.v_mu[i];
+      mu = adam1(a.w_mu[i], g, mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+      a.m_mu[i] = mm; a.v_mu[i] = vv;
+    }
+    a.w_mu[i] = mu;
     mm = a.m_sg[i]; vv = a.v_sg[i];
     const float sg = adam1(a.w_sigma[i], __fmul_rn(g, nz), mm, vv, a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
     a.m_sg[i] = mm; a.v_sg[i] = vv; a.w_sigma[i] = sg;

@@ -344,7 +344,9 @@ int hb_noisy_adam(float* w_dev, float* w_mu_dev, float* w_sigma_dev, const float
                   const float* step_dev, void* eff_dev, int32_t eff_dtype, int64_t n, int32_t cols, int32_t eff_ld, float lr,
                   float beta1, float beta2, float eps, void* stream);
 
-/* The same for up to 8 merged tensors (all layers' weights and biases) in ONE launch.        */
+/* The same for up to 8 merged tensors (all layers' weights and biases) in ONE launch. w and w_mu see the same
+ * gradient at every step, so their moments stay equal: m_mu == m_w and v_mu == v_w may be passed as the SAME arrays, and
+ * w's step is then applied to w_mu without a second pass over the moments.                     */
 typedef struct hb_adam_tensor {
   float *w, *w_mu, *w_sigma;
   const float* noise;

@@ -378,3 +378,36 @@ def test_mfma_actor_equals_library_actor(n, players):
             qb = q_old[bad, a_old[bad].long()]
             assert (qa - qb).abs().max().item() < 1e-3
         assert (legal[torch.arange(n, device="cuda"), a_new.long()] == 1).all()
+
+
+def test_adam_shared_moments_equal_separate_moments():
+    """Passing the same moment arrays for w and w_mu (they see the same gradient, so their moments are equal) gives
+    bit-identical parameters and effective weights to separate, equal moment arrays — vector and scalar kernels."""
+    import torch
+
+    from hanabi_hip import _capi as K
+
+    g = torch.Generator(device="cuda").manual_seed(4)
+    L, s = K.lib(), K.current_stream()
+    for rows, cols in ((32, 64), (7, 5)):      # (vector path, scalar path: cols % 4 != 0)
+        mk = lambda sc=1.0: torch.randn(rows, cols, device="cuda", generator=g) * sc
+        base, noise, grad = [mk(0.1) for _ in range(3)], mk(), mk(0.01)
+        m0, v0, ms, vs = mk(1e-3), mk(1e-3).abs(), mk(1e-3), mk(1e-3).abs()
+        step = torch.tensor(3.0, device="cuda")
+        outs = []
+        for shared in (False, True):
+            p = [t.clone() for t in base]
+            m_w, v_w, m_s, v_s = m0.clone(), v0.clone(), ms.clone(), vs.clone()
+            m_mu, v_mu = (m_w, v_w) if shared else (m0.clone(), v0.clone())
+            eff = torch.zeros(rows, cols, device="cuda")
+            tab = (K.HbAdamTensor * 1)()
+            d = tab[0]
+            d.w, d.w_mu, d.w_sigma = (t.data_ptr() for t in p)
+            d.noise, d.grad, d.grad_dtype, d.grad_ld = noise.data_ptr(), grad.data_ptr(), 0, 0
+            d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma = (t.data_ptr() for t in (m_w, v_w, m_mu, v_mu, m_s, v_s))
+            d.eff, d.n, d.cols, d.eff_ld = eff.data_ptr(), rows * cols, cols, cols
+            for _ in range(3):
+                K.check(L.hb_noisy_adam_multi(tab, 1, K.dptr(step), 1.0, 0, 1e-3, 0.9, 0.999, 3.125e-5, s))
+            outs.append(p + [m_w, v_w, m_mu, v_mu, m_s, v_s, eff])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
