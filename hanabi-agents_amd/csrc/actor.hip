@@ -284,31 +284,43 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
 }
 
 // weights [K][N] (row stride w_ld) -> transposed [n'][k_pad] with n' = (n / group_cols) * 256 + n % group_cols
-// (group_cols = 0: n' = n); bias -> fp32 at the same n'. 32 x 32 tiles through LDS. Rows / columns that no input
-// maps to are left untouched (the caller zero-initialises the outputs once).
-__global__ __launch_bounds__(256) void pack_weights_kernel(const __hip_bfloat16* __restrict__ w, int k_rows, int n_cols, int w_ld,
-                                                           const __hip_bfloat16* __restrict__ bias, int group_cols,
-                                                           __hip_bfloat16* __restrict__ wt, int k_pad, float* __restrict__ bias_out) {
+// (group_cols = 0: n' = n); bias -> fp32 at the same n'. 32 x 32 tiles through LDS; up to 4 matrices per launch
+// (workgroup b belongs to job j where first[j] <= b < first[j + 1]). Rows / columns that no input maps to are left
+// untouched (the caller zero-initialises the outputs once).
+struct PackJobs {
+  hb_pack_job j[4];
+  int first[5];
+  int count;
+};
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackJobs jobs) {
   __shared__ __hip_bfloat16 t[32][33];
+  int ji = 0;
+  while (ji + 1 < jobs.count && static_cast<int>(blockIdx.x) >= jobs.first[ji + 1]) ++ji;
+  const hb_pack_job& job = jobs.j[ji];
+  const __hip_bfloat16* w = static_cast<const __hip_bfloat16*>(job.w);
+  const __hip_bfloat16* bias = static_cast<const __hip_bfloat16*>(job.bias);
+  __hip_bfloat16* wt = static_cast<__hip_bfloat16*>(job.wt);
+  const int tiles_n = (job.n_cols + 31) / 32;
+  const int b = static_cast<int>(blockIdx.x) - jobs.first[ji];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int k0 = (b / tiles_n) * 32, n0 = (b % tiles_n) * 32;
   for (int i = ty; i < 32; i += 8) {
     const int k = k0 + i, n = n0 + tx;
-    t[i][tx] = (k < k_rows && n < n_cols) ? w[static_cast<long long>(k) * w_ld + n] : __float2bfloat16(0.f);
+    t[i][tx] = (k < job.k_rows && n < job.n_cols) ? w[static_cast<long long>(k) * job.w_ld + n] : __float2bfloat16(0.f);
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int n = n0 + i, k = k0 + tx;
-    if (n < n_cols && k < k_pad) {
-      const int np = group_cols ? (n / group_cols) * 256 + n % group_cols : n;
-      wt[static_cast<long long>(np) * k_pad + k] = t[tx][i];
+    if (n < job.n_cols && k < job.k_pad) {
+      const int np = job.group_cols ? (n / job.group_cols) * 256 + n % job.group_cols : n;
+      wt[static_cast<long long>(np) * job.k_pad + k] = t[tx][i];
     }
   }
-  if (blockIdx.y == 0 && ty == 0) {
+  if (k0 == 0 && ty == 0) {
     const int n = n0 + tx;
-    if (n < n_cols) {
-      const int np = group_cols ? (n / group_cols) * 256 + n % group_cols : n;
-      bias_out[np] = __bfloat162float(bias[n]);
+    if (n < job.n_cols) {
+      const int np = job.group_cols ? (n / job.group_cols) * 256 + n % job.group_cols : n;
+      job.bias_out[np] = __bfloat162float(bias[n]);
     }
   }
 }
@@ -366,15 +378,24 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 extern "C" {
 
-int hb_actor_pack_weights(const void* w_dev, int32_t k_rows, int32_t n_cols, int32_t w_ld, const void* bias_dev, int32_t group_cols,
-                          void* wt_dev, int32_t k_pad, float* bias_out_dev, void* stream) {
-  if (!w_dev || !bias_dev || !wt_dev || !bias_out_dev) return fail(HB_ERR_INVALID, "null argument");
-  if (k_rows < 1 || n_cols < 1 || w_ld < n_cols || k_pad < k_rows || k_pad % 64) return fail(HB_ERR_INVALID, "need w_ld >= n_cols, k_pad >= k_rows and k_pad a multiple of 64");
-  if (group_cols < 0 || group_cols > 256) return fail(HB_ERR_INVALID, "group_cols must be 0..256");
-  const dim3 grid((n_cols + 31) / 32, (k_pad + 31) / 32);
-  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __hip_bfloat16*>(w_dev),
-                     k_rows, n_cols, w_ld, static_cast<const __hip_bfloat16*>(bias_dev), group_cols, static_cast<__hip_bfloat16*>(wt_dev),
-                     k_pad, bias_out_dev);
+int hb_actor_pack_weights(const hb_pack_job* jobs, int32_t count, void* stream) {
+  if (!jobs) return fail(HB_ERR_INVALID, "null argument");
+  if (count < 1 || count > 4) return fail(HB_ERR_INVALID, "count must be 1..4");
+  PackJobs p{};
+  p.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const hb_pack_job& j = jobs[i];
+    if (!j.w || !j.bias || !j.wt || !j.bias_out) return fail(HB_ERR_INVALID, "null pointer in job %d", i);
+    if (j.k_rows < 1 || j.n_cols < 1 || j.w_ld < j.n_cols || j.k_pad < j.k_rows || j.k_pad % 64)
+      return fail(HB_ERR_INVALID, "job %d: need w_ld >= n_cols, k_pad >= k_rows and k_pad a multiple of 64", i);
+    if (j.group_cols < 0 || j.group_cols > 256) return fail(HB_ERR_INVALID, "job %d: group_cols must be 0..256", i);
+    p.j[i] = j;
+    p.first[i] = blocks;
+    blocks += ((j.n_cols + 31) / 32) * ((j.k_pad + 31) / 32);
+  }
+  p.first[count] = blocks;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

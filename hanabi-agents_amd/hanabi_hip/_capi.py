@@ -44,6 +44,13 @@ class HbAdamTensor(C.Structure):
                                                                                    ("grad_dtype", C.c_int32), ("grad_ld", C.c_int32)]
 
 
+class HbPackJob(C.Structure):
+    """`hb_pack_job` of include/hanabi_hip.h."""
+
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("wt", C.c_void_p), ("bias_out", C.c_void_p)] + [
+        (n, C.c_int32) for n in ("k_rows", "n_cols", "w_ld", "group_cols", "k_pad")]
+
+
 class HbRule(C.Structure):
     """`hb_rule` of include/hanabi_hip.h."""
 
@@ -112,7 +119,7 @@ SIGNATURES = {
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "hb_noisy_adam": (C.c_int, [_P] * 11 + [_P, _P, _I32, _I64, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_noisy_adam_multi": (C.c_int, [C.POINTER(HbAdamTensor), _I32, _P, C.c_float, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
-    "hb_actor_pack_weights": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _P]),
+    "hb_actor_pack_weights": (C.c_int, [C.POINTER(HbPackJob), _I32, _P]),
     "hb_actor_hidden": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
     "hb_actor_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P]),
     "hb_policy_select": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _U64, _U64, _I64, _P, _P]),

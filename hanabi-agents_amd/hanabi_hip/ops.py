@@ -66,12 +66,14 @@ class ActorMFMA:
 
     def pack(self, w1, b1, w2, b2):
         """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K]."""
-        L, s = K.lib(), K.current_stream()
         ak = self.n_actions * self.n_atoms
-        K.check(L.hb_actor_pack_weights(K.dptr(w1), self.obs_len, self.hidden, w1.stride(0), K.dptr(b1), 0, K.dptr(self.w1t),
-                                        self.k_pad, K.dptr(self.b1), s))
-        K.check(L.hb_actor_pack_weights(K.dptr(w2), self.hidden, ak, w2.stride(0), K.dptr(b2), self.group_actions * self.n_atoms,
-                                        K.dptr(self.w2t), self.hidden, K.dptr(self.b2), s))
+        jobs = (K.HbPackJob * 2)()
+        for j, (w, b, wt, bo, k_rows, n_cols, group, kp) in enumerate((
+                (w1, b1, self.w1t, self.b1, self.obs_len, self.hidden, 0, self.k_pad),
+                (w2, b2, self.w2t, self.b2, self.hidden, ak, self.group_actions * self.n_atoms, self.hidden))):
+            jobs[j].w, jobs[j].bias, jobs[j].wt, jobs[j].bias_out = w.data_ptr(), b.data_ptr(), wt.data_ptr(), bo.data_ptr()
+            jobs[j].k_rows, jobs[j].n_cols, jobs[j].w_ld, jobs[j].group_cols, jobs[j].k_pad = k_rows, n_cols, w.stride(0), group, kp
+        K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))   # both layers in one launch
 
     def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0):
         n = obs.shape[0]

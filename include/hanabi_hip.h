@@ -371,9 +371,9 @@ int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int64_t act_ld /* row 
 
 /* ---- actor forward on MFMA (csrc/actor.hip): rlax_rainbow.py:113-122,141-150 over noisy_mlp.py:176-185 ------------
  * For the C51 network with ONE hidden layer and bf16 effective weights W = w + w_mu + w_sigma * eps:
- *   hb_actor_pack_weights  the GEMM kernels want both operands k-contiguous: W [k_rows, n_cols] (row stride w_ld, bf16)
- *                          -> wt_dev [n', k_pad] bf16 with n' = (n / group_cols) * 256 + n % group_cols (group_cols = 0:
- *                          n' = n) and bias (bf16 [n_cols]) -> bias_out_dev (fp32, at n'). Entries no input maps to are
+ *   hb_actor_pack_weights  the GEMM kernels want both operands k-contiguous: per job, W [k_rows, n_cols] (row stride w_ld,
+ *                          bf16) -> wt [n', k_pad] bf16 with n' = (n / group_cols) * 256 + n % group_cols (group_cols = 0:
+ *                          n' = n) and bias (bf16 [n_cols]) -> bias_out (fp32, at n'). Entries no input maps to are
  *                          not written: zero-initialise both outputs once. For the output layer use group_cols =
  *                          (256 / n_atoms) * n_atoms (255 for 51 atoms), so that every 256-column tile holds whole actions.
  *   hb_actor_hidden        h_dev [n_rows, hidden] bf16 = relu(obs @ W1 + b1); obs_dev int8 [n_rows, obs_len] with entries in
@@ -383,8 +383,15 @@ int hb_relu_bwd_colsum(void* dy_dev, const void* act_dev, int64_t act_ld /* row 
  *                          117-118); w2t_dev [ceil(n_actions / (256 / n_atoms)) * 256, hidden] packed as above. The logits
  *                          are rounded to bf16 before the softmax, like the output of a bf16 GEMM.
  *   hb_policy_select       the selection half of hb_policy_act on precomputed q (same Philox draws, same tie rule).   */
-int hb_actor_pack_weights(const void* w_dev, int32_t k_rows, int32_t n_cols, int32_t w_ld, const void* bias_dev,
-                          int32_t group_cols, void* wt_dev, int32_t k_pad, float* bias_out_dev, void* stream);
+typedef struct hb_pack_job {
+  const void* w;      /* bf16 [k_rows, n_cols], row stride w_ld */
+  const void* bias;   /* bf16 [n_cols] */
+  void* wt;           /* bf16 [n', k_pad] */
+  float* bias_out;    /* fp32 [n'] */
+  int32_t k_rows, n_cols, w_ld, group_cols, k_pad;
+} hb_pack_job;
+int hb_actor_pack_weights(const hb_pack_job* jobs /* host array of device pointers */, int32_t count /* 1..4: one launch */,
+                          void* stream);
 int hb_actor_hidden(const int8_t* obs_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev, int32_t k_pad,
                     const float* b1_dev, int32_t hidden, void* h_dev, void* stream);
 int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev,

@@ -23,8 +23,11 @@ lib, s = K.lib(), K.current_stream()
 w1t = torch.zeros(H, Kp, device=dev, dtype=torch.bfloat16); b1p = torch.zeros(H, device=dev)
 groups = (A + 4) // 5
 w2t = torch.zeros(groups * 256, H, device=dev, dtype=torch.bfloat16); b2p = torch.zeros(groups * 256, device=dev)
-K.check(lib.hb_actor_pack_weights(K.dptr(w1), L, H, H, K.dptr(b1), 0, K.dptr(w1t), Kp, K.dptr(b1p), s))
-K.check(lib.hb_actor_pack_weights(K.dptr(w2), H, A * NA, Np, K.dptr(b2), 255, K.dptr(w2t), H, K.dptr(b2p), s))
+jobs = (K.HbPackJob * 2)()
+for j, (w, b, wt, bo, kr, nc, ld, grp, kp) in enumerate(((w1, b1, w1t, b1p, L, H, H, 0, Kp), (w2, b2, w2t, b2p, H, A * NA, Np, 255, H))):
+    jobs[j].w, jobs[j].bias, jobs[j].wt, jobs[j].bias_out = w.data_ptr(), b.data_ptr(), wt.data_ptr(), bo.data_ptr()
+    jobs[j].k_rows, jobs[j].n_cols, jobs[j].w_ld, jobs[j].group_cols, jobs[j].k_pad = kr, nc, ld, grp, kp
+K.check(lib.hb_actor_pack_weights(jobs, 2, s))
 assert torch.equal(w1t[:, :L], w1[:L].t()) and torch.equal(b1p, b1.float())
 n = torch.arange(A * NA, device=dev); npr = n // 255 * 256 + n % 255
 assert torch.equal(w2t[npr], w2[:, :A * NA].t()) and torch.equal(b2p[npr], b2[:A * NA].float())
