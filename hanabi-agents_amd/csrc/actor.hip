@@ -22,7 +22,9 @@
 // Roofline: MFMA (bf16 dense 2.5 PFLOP/s). LDS fragment traffic is 0.375 KB per MFMA. Measured at 32 768 rows
 // (scripts/actor_mfma_probe.py): hidden 33 us, q 43 us (GEMM 37 + C51 epilogue), select ~3 us = 85 us against 124 us for
 // hb_obs_cast + hipBLASLt GEMMs + hb_policy_act; ~0.75 PFLOP/s executed. One barrier per K step keeps the MFMA pipe
-// ~64 % busy (both wavefronts of a SIMD reach the barrier together); s_setprio around the MFMA block changed nothing.
+// ~64 % busy (both wavefronts of a SIMD reach the barrier together); s_setprio around the MFMA block changed nothing, and
+// a variant with 128-row tiles, K step 32 and two workgroups per CU (66.5 KB LDS each) measured slower (hidden 34.3 vs
+// 33.2 us, q 47.0 vs 43.5 us).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
@@ -330,11 +332,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackJobs jobs) 
 __global__ __launch_bounds__(256) void policy_select_kernel(const float* __restrict__ q, const int8_t* __restrict__ legal, long long n,
                                                             int A, float epsilon, unsigned long long seed, unsigned long long draw,
                                                             long long first_gid, int32_t* __restrict__ actions) {
-  __shared__ float sq[256 * 65];
-  __shared__ int8_t sl[256 * 65];
+  extern __shared__ float sq[];                                    // 256 * (A | 1) floats, then as many bytes
   const long long g0 = static_cast<long long>(blockIdx.x) * 256;
   const int ng = n - g0 < 256 ? static_cast<int>(n - g0) : 256;
   const int ld = A | 1;
+  int8_t* sl = reinterpret_cast<int8_t*>(sq + 256 * ld);
   for (int e = threadIdx.x; e < ng * A; e += 256) {
     const int gg = e / A, i = e - gg * A;
     sq[gg * ld + i] = q[g0 * A + e];
@@ -373,7 +375,6 @@ __global__ __launch_bounds__(256) void policy_select_kernel(const float* __restr
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 }  // namespace
 
 extern "C" {
@@ -441,8 +442,8 @@ int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_game
   if (!q_dev || !legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
   if (n_games <= 0) return HB_OK;
-  hipLaunchKernelGGL(policy_select_kernel, dim3(static_cast<unsigned>((n_games + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), q_dev, legal_dev, static_cast<long long>(n_games), n_actions, epsilon,
+  hipLaunchKernelGGL(policy_select_kernel, dim3(static_cast<unsigned>((n_games + 255) / 256)), dim3(256),
+                     static_cast<size_t>(256) * (n_actions | 1) * 5, static_cast<hipStream_t>(stream), q_dev, legal_dev, static_cast<long long>(n_games), n_actions, epsilon,
                      static_cast<unsigned long long>(seed), static_cast<unsigned long long>(draw), static_cast<long long>(first_game_id),
                      actions_dev);
   HB_HIP(hipGetLastError());
