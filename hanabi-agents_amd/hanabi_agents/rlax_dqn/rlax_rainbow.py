@@ -460,7 +460,9 @@ class DQNAgent:
             # stratified uniforms drawn inside the sampling kernel, keyed by (seed; query, optimizer step): no
             # generator launch, and nothing for HIP-graph replay to re-seed (torch re-fills the generator's seed /
             # offset tensors with two more launches before every replay of a graph that contains torch.rand)
-            return self.experience.sum_tree.per_sample_philox_dev(self.params.seed + 0x51ED270B, self._fl.step, b)
+            # (keyed by the shard too: data-parallel ranks share the seed but must not draw the same strata offsets)
+            return self.experience.sum_tree.per_sample_philox_dev(self.params.seed + 0x51ED270B + 0x9E3779B1 * self.first_game_id,
+                                                                  self._fl.step, b)
         if self.params.use_priority:
             u = torch.rand(b, dtype=torch.float64, device=self.device)  # scaled to [0, 1/B) inside the kernel
             return self.experience.sum_tree.per_sample_dev(u, unit=True)

@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -85,3 +86,53 @@ def test_rank_shards_use_disjoint_reproducible_decks():
         part = O.OracleEnv(cfg, 32, seed=1234, first_game_id=rank * 32).export_state()
         assert np.array_equal(part, whole[rank * 32:(rank + 1) * 32])
     assert len({bytes(r[16:29].tobytes()) for r in whole}) == 64   # all decks differ
+
+
+def _gpu_worker(rank, world, port, out):
+    """Full self-play + fused learner (packed all-reduce bucket, HIP graphs around the collective, learner stream, MFMA
+    actor) with two ranks sharing ONE GPU; gloo moves the CUDA gradient bucket (RCCL needs one GPU per rank)."""
+    for p in (ROOT, os.path.join(ROOT, "hanabi-agents_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    torch.cuda.set_device(0)
+    n = 128
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=n, seed=9, first_game_id=rank * n)
+    params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=n * 8, layers=[256], compute_dtype="bfloat16",
+                               mask_terminal=True, target_update_period=5)
+    agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=40 + s), device="cuda")
+              for s in (0, 1)]
+    for a in agents:
+        a.first_game_id = rank * n
+    sess = SelfPlaySession(env, agents)
+    assert sess.overlap_allreduce or sess.learner_stream is not None
+    w0 = torch.cat([p.detach().reshape(-1) for p in agents[0].online.parameters()]).cpu()
+    sess.run(24)
+    torch.cuda.synchronize()
+    fl = agents[0]._fl
+    assert fl is not None and not fl.direct and fl.actor is not None and agents[0]._graph1 is not None
+    w = [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]).cpu() for a in agents]
+    eff = torch.cat([t.float().reshape(-1) for pair in fl.eff for t in pair]).cpu()
+    rows = env.export_state().cpu()
+    torch.save({"w": w, "w0": w0, "eff": eff, "rows": rows, "grad_steps": sess.grad_steps, "illegal": env.illegal_count()},
+               os.path.join(out, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_stay_in_lock_step(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"g{i}.pt") for i in range(world)]
+    assert r[0]["grad_steps"] == r[1]["grad_steps"] > 0 and r[0]["illegal"] == r[1]["illegal"] == 0
+    assert not torch.equal(r[0]["rows"], r[1]["rows"])                     # different games on each rank (Philox by global id)
+    for a, b in zip(r[0]["w"], r[1]["w"]):
+        assert torch.equal(a, b)                                           # averaged gradients -> identical replicas
+    assert torch.equal(r[0]["eff"], r[1]["eff"]) and not torch.equal(r[0]["w"][0], r[0]["w0"])
