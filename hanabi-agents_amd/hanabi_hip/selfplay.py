@@ -19,6 +19,8 @@ the learner ignores when `mask_terminal` is on).
 """
 import torch
 
+from . import _capi as K
+
 
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
@@ -45,6 +47,7 @@ class SelfPlaySession:
             # (a torch.cuda.Stream / ExternalStream may be passed in, e.g. one restricted to a CU subset: streams.py)
             self.learner_stream = learner_stream if isinstance(learner_stream, torch.cuda.Stream) else torch.cuda.Stream(
                 device=env.device, priority=learner_priority)
+        self._main, self._main_raw = None, -1
         self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
         self.env_steps = 0
         self.grad_steps = 0
@@ -55,7 +58,12 @@ class SelfPlaySession:
         env = self.env
         seat = self.t % env.players
         agent = self.agents[seat]
-        main = torch.cuda.current_stream() if self.learner_stream is not None else None
+        main = None
+        if self.learner_stream is not None:
+            raw = K.current_stream().value  # (torch.cuda.current_stream() costs ~8 us of Python: look it up only when it changed)
+            if raw != self._main_raw:
+                self._main, self._main_raw = torch.cuda.current_stream(), raw
+            main = self._main
         if main is not None and id(agent) in self._update_done:
             main.wait_event(self._update_done.pop(id(agent)))  # its replay / weights are being written by that update
         # [0]: the rich observation source for agents with requires_vectorized_observation() False (rule-based

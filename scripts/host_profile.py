@@ -1,0 +1,25 @@
+"""cProfile of the host side of the self-play step (where do the ~0.15 ms of enqueue time go?)."""
+import cProfile, os, pstats, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hanabi-agents_amd"))
+import hanabi_hip
+from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+from hanabi_hip.selfplay import SelfPlaySession
+
+n = 32768
+flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=1234)
+params = RlaxRainbowParams(compute_dtype="bfloat16", mask_terminal=True)
+agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s), device="cuda") for s in (0, 1)]
+sess = SelfPlaySession(env, agents)
+for _ in range(60):
+    sess.step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(400):
+    sess.step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(28)
