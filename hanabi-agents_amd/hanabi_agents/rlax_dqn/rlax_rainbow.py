@@ -346,7 +346,8 @@ class DQNAgent:
     # the flat buffer and STARTS the RCCL all-reduce without blocking; update_finish() waits for it and applies
     # Adam / priorities / target sync. A driver that alternates agents (hanabi_hip.selfplay) runs the next seat's
     # replay insert, policy and env step between the two calls, so the ~3.4 MB gradient exchange over xGMI hides
-    # behind ~0.2 ms of independent work. With one rank the pair is exactly update().
+    # behind ~0.2 ms of independent work. With one rank the pair is exactly update() — and, under HIP graphs, the whole
+    # update (Adam included) is one graph launched by update_begin(): do not let anything read the weights between the two.
     def update_begin(self):
         assert self._pending is None, "update_finish() of the previous update has not been called"
         self.experience.sync_size()
@@ -371,7 +372,8 @@ class DQNAgent:
         self._pending = None
         self._finish_allreduce(work)
         if part2_args is None:
-            self._graph2.replay()
+            if self._graph2 is not None:  # (single rank: the second half was captured into the first graph)
+                self._graph2.replay()
         else:
             self._update_part2(*part2_args)
         self._eff_cache = None
@@ -524,6 +526,13 @@ class DQNAgent:
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog polling its events in a
         # data-parallel run) must not invalidate the capture
+        if self._dp_world() == 1:
+            # no collective between the halves: one graph, one launch (graph2 stays empty-handed: see update_finish)
+            with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
+                self.last_loss, self._g_idx, self._g_prios = self._update_part1()
+                self._update_part2(self._g_idx, self._g_prios)
+            self._graph2 = None
+            return
         with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
             self.last_loss, self._g_idx, self._g_prios = self._update_part1()
         with torch.cuda.graph(self._graph2, pool=self._graph1.pool(), capture_error_mode="thread_local"):
