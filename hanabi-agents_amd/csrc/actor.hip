@@ -24,7 +24,8 @@
 // hb_obs_cast + hipBLASLt GEMMs + hb_policy_act; ~0.75 PFLOP/s executed. One barrier per K step keeps the MFMA pipe
 // ~64 % busy (both wavefronts of a SIMD reach the barrier together); s_setprio around the MFMA block changed nothing, and
 // a variant with 128-row tiles, K step 32 and two workgroups per CU (66.5 KB LDS each) measured slower (hidden 34.3 vs
-// 33.2 us, q 47.0 vs 43.5 us).
+// 33.2 us, q 47.0 vs 43.5 us); so did a two-group schedule (memory segment | barrier | MFMA segment | barrier, the two
+// row halves one barrier apart: 39.3 / 46.1 us) — it gives up the ds_read / MFMA interleaving inside each wavefront.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
