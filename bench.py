@@ -327,6 +327,37 @@ def qnet_roofline(agent, env, args):
     learn_s = a.elapsed_time(b) / 1e3 / reps
     peak = MFMA_PEAK_TFLOPS[args.compute_dtype]
     actor_tf = fwd_flop * n / actor_s / 1e12
+    per_kernel = None
+    fl0 = getattr(agent, "_fl", None)
+    if fl0 is not None and fl0.actor is not None and agent.use_mfma_actor:
+        # each hand-written kernel alone (events around back-to-back launches; executed FLOPs of its GEMM)
+        from hanabi_hip import _capi as K
+
+        ac, L, s = fl0.actor, K.lib(), K.current_stream()
+        obs8, legal8, support = env.obs, env.legal, agent.atoms[0].contiguous()
+        acts = torch.empty(n, dtype=torch.int32, device=env.obs.device)
+        launches = {
+            "hb_actor_hidden": lambda: L.hb_actor_hidden(K.dptr(obs8), n, ac.obs_len, K.dptr(ac.w1t), ac.k_pad, K.dptr(ac.b1), ac.hidden,
+                                                         K.dptr(ac.h), s),
+            "hb_actor_q": lambda: L.hb_actor_q(K.dptr(ac.h), n, ac.hidden, K.dptr(ac.w2t), K.dptr(ac.b2), K.dptr(support), ac.n_actions,
+                                               ac.n_atoms, K.dptr(ac.q), s),
+            "hb_policy_select": lambda: L.hb_policy_select(K.dptr(ac.q), K.dptr(legal8), n, ac.n_actions, 0.1, 1, 1, 0, K.dptr(acts), s),
+        }
+        flops = {"hb_actor_hidden": 2.0 * ac.k_pad * ac.hidden * n, "hb_actor_q": 2.0 * ac.hidden * ac.w2t.shape[0] * n}
+        per_kernel = {}
+        for name, fn in launches.items():
+            for _ in range(3):
+                fn()
+            a.record()
+            for _ in range(20):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / 20 * 1e3
+            per_kernel[name] = {"avg_launch_us": us}
+            if name in flops:
+                tf = flops[name] / (us * 1e-6) / 1e12
+                per_kernel[name].update(executed_gflop=flops[name] / 1e9, achieved=tf, frac=tf / peak)
     # what the actor kernels execute: merged weights (one GEMM per layer), K padded to a multiple of 64, output columns in
     # 256-column groups of whole actions (csrc/actor.hip)
     fl = getattr(agent, "_fl", None)
@@ -341,7 +372,8 @@ def qnet_roofline(agent, env, args):
                               "frac": actor_tf / peak, "executed_gflop": exec_flop * n / 1e9, "executed_achieved": exec_tf,
                               "executed_frac": exec_tf / peak,
                               "kernels": ("hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
-                                          if mfma_actor else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act")},
+                                          if mfma_actor else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act"),
+                              "per_kernel": per_kernel},
             "learner_update": {"batch": 256, "algorithmic_gflop": 5.0 * 256 * fwd_flop / 1e9, "ms": learn_s * 1e3,
                                "achieved": learn_tf, "frac": learn_tf / peak, "grad_steps_per_sec_alone": 1.0 / learn_s}}
 
