@@ -77,3 +77,39 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("oracle_py", "liboracle", "from oracle", "import oracle", "orc_"):
                     assert needle not in text, f"{f} references the oracle ({needle})"
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point checks its arguments before it touches the device: bad calls come back with a negative code and a
+    message, never a crash — also on a machine without a GPU (nothing here launches anything)."""
+    import hanabi_hip
+    from hanabi_hip import _capi as K
+
+    L = hanabi_hip.lib()
+    cfg = hanabi_hip.make_config()
+    one = C.c_void_p(16)      # a non-null, 16-byte aligned fake pointer: validation must reject the call before using it
+    assert L.hb_actor_hidden(None, 10, 658, one, 704, one, 512, one, None) < 0 and b"null" in L.hb_last_error()
+    assert L.hb_actor_hidden(one, 10, 658, one, 700, one, 512, one, None) < 0 and b"multiple of 64" in L.hb_last_error()
+    assert L.hb_actor_hidden(one, 10, 658, one, 704, one, 500, one, None) < 0 and b"multiple of 256" in L.hb_last_error()
+    assert L.hb_actor_hidden(one, 0, 658, one, 704, one, 512, one, None) == 0            # empty batch: no-op
+    assert L.hb_actor_q(one, 10, 500, one, one, one, 20, 51, one, None) < 0
+    assert L.hb_actor_q(one, 10, 512, one, one, one, 20, 300, one, None) < 0 and b"n_atoms" in L.hb_last_error()
+    assert L.hb_actor_q(one, 0, 512, one, one, one, 20, 51, one, None) == 0
+    assert L.hb_policy_select(one, one, 5, 65, 0.1, 1, 1, 0, one, None) < 0
+    assert L.hb_policy_select(one, one, 0, 20, 0.1, 1, 1, 0, one, None) == 0
+    jobs = (K.HbPackJob * 1)()
+    assert L.hb_actor_pack_weights(jobs, 1, None) < 0 and b"null pointer in job 0" in L.hb_last_error()
+    assert L.hb_actor_pack_weights(jobs, 5, None) < 0
+    rules = (K.HbRule * 1)()
+    rules[0].kind = 99
+    assert L.hb_rule_act(C.byref(cfg), one, 4, 0, rules, 1, 1, 1, one, None, None) < 0 and b"unknown kind" in L.hb_last_error()
+    assert L.hb_rule_act(C.byref(cfg), one, 4, 0, rules, 17, 1, 1, one, None, None) < 0
+    assert L.hb_rule_act(C.byref(cfg), one, 0, 0, rules, 0, 1, 1, one, None, None) == 0
+    assert L.hb_relu_bwd_colsum(one, one, 4, 1, 8, 8, one, None) < 0 and b"act_ld" in L.hb_last_error()
+    assert L.hb_colsum(None, 1, 8, 8, one, None) < 0
+    tab = (K.HbAdamTensor * 1)()
+    assert L.hb_noisy_adam_multi(tab, 1, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0 and b"tensor 0" in L.hb_last_error()
+    assert L.hb_noisy_adam_multi(tab, 9, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0
+    assert L.hb_per_sample_philox(None, 1, one, 4, one, one, None) < 0
+    assert L.hb_tree_import_nodes(None, one, None) < 0
+    assert L.hb_env_state(None) is None
