@@ -187,3 +187,23 @@ def test_episode_statistics_counted_in_kernel():
         episodes += int(out["terminal"].sum())
         score += int((out["score"] * out["terminal"]).sum())
     assert episodes > 100 and env.stats() == (episodes, score)
+
+
+@pytest.mark.parametrize("game", ["Hanabi-Full", "Hanabi-Small", "Hanabi-Very-Small"])
+@pytest.mark.parametrize("players", [2, 3, 4, 5])
+def test_arbitrary_uids_all_variants(game, players):
+    """Every compiled variant under move uids drawn uniformly from [-2, A+2): about half of them illegal (discard at
+    max tokens, hints nobody matches, empty slots late in a game, out of range). Illegal moves leave the state alone
+    and are counted; everything stays bit-identical to the oracle, with and without the lenient-reward flag."""
+    import torch
+
+    for extra in (0, O.FLAG_LENIENT_REWARD):
+        env, orc = _pair(game, players, 96, seed=31 + players, flags=O.FLAG_AUTO_RESET | extra, first_game_id=7)
+        rng = np.random.default_rng(players * 10 + len(game))
+        for t in range(70):
+            act = rng.integers(-2, env.num_actions + 2, 96).astype(np.int32)
+            if t % 3 == 0:                                     # keep the games moving: a third of the steps are legal
+                act = env.random_legal_actions(seed=9, draw=t).cpu().numpy()
+            env.step(torch.as_tensor(act).cuda())
+            _assert_same(env, orc, orc.step(act), f"{game}/{players}p flags {extra} step {t}")
+        assert env.illegal_count() == orc.illegal_count() > 0
