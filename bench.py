@@ -268,8 +268,9 @@ def main():
         "dtype": "u8" if args.env_only else f"u8 env/encoder + {args.compute_dtype} Q-net GEMM (fp32 accumulate, fp32 master weights)",
         "data": "synthetic",
         "config": {
-            "workload": ("2-player full Hanabi, 32 768 envs, Rainbow (PER sum_tree + noisy C51) on 1 MI355X"
-                         if (n == 32768 and args.players == 2) else f"{args.players}-player full Hanabi, {n} envs per GPU"),
+            "workload": (("2-player full Hanabi, 32 768 envs, Rainbow (PER sum_tree + noisy C51) on 1 MI355X"
+                          if (n == 32768 and args.players == 2) else f"{args.players}-player full Hanabi, {n} envs per GPU")
+                         + (f" x {world} GPUs (weak scaling: the same per GPU)" if world > 1 else "")),
             "games_per_gpu": n, "players": args.players, "train_batch": 256, "updates_per_step": args.updates_per_step,
             "policy": "random-legal (env only)" if args.env_only else "agent eps-greedy (eps 0.1)",
             "parallelism": f"dp{world}: games sharded, RCCL gradient all-reduce",
