@@ -163,11 +163,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    # rehearsal knobs (one-GPU box): HB_BENCH_DEVICE pins every rank to one device, HB_DIST_BACKEND=gloo replaces RCCL,
+    # which needs one GPU per rank. The driver sets neither.
+    if "HB_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["HB_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("HB_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import hanabi_hip
