@@ -48,6 +48,10 @@ class SelfPlaySession:
             self.learner_stream = learner_stream if isinstance(learner_stream, torch.cuda.Stream) else torch.cuda.Stream(
                 device=env.device, priority=learner_priority)
         self._main, self._main_raw = None, -1
+        import torch.distributed as dist
+
+        self._dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self._lstreams = {}
         self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
         self.env_steps = 0
         self.grad_steps = 0
@@ -86,16 +90,29 @@ class SelfPlaySession:
         if self.learner_stream is None:
             self._train_inline(agent, seat, train)
         elif train and seat in self.train_seats and self._ready(agent):
-            with torch.cuda.stream(self.learner_stream):
-                self.learner_stream.wait_event(acted)
+            ls = self._learner_stream_of(agent)
+            with torch.cuda.stream(ls):
+                ls.wait_event(acted)
                 for _ in range(self.updates_per_step):
                     agent.update_begin()
                     agent.update_finish()
                     self.grad_steps += 1
                 done = torch.cuda.Event()
-                done.record(self.learner_stream)
+                done.record(ls)
             self._update_done[id(agent)] = done
         self.t += 1
+
+    def _learner_stream_of(self, agent):
+        """One learner stream with a single rank (measured best: 0.195 ms per step). Data-parallel: one per agent, so that
+        seat A's gradient all-reduce (tens of microseconds of xGMI latency in the middle of its update) is in flight while
+        seat B's update computes, instead of both queueing on one stream whose updates would then outlast a step."""
+        if not self._dp:
+            return self.learner_stream
+        ls = self._lstreams.get(id(agent))
+        if ls is None:
+            ls = self._lstreams[id(agent)] = (self.learner_stream if not self._lstreams else
+                                              torch.cuda.Stream(device=self.env.device, priority=self.learner_stream.priority))
+        return ls
 
     def _ready(self, agent):
         if not hasattr(agent, "experience"):  # passive partner (rule-based): nothing to train
@@ -125,6 +142,8 @@ class SelfPlaySession:
             self._inflight = None
         if self.learner_stream is not None:
             torch.cuda.current_stream().wait_stream(self.learner_stream)
+            for ls in self._lstreams.values():
+                torch.cuda.current_stream().wait_stream(ls)
             self._update_done.clear()
 
     def run(self, steps, train=True):
