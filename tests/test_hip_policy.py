@@ -325,8 +325,9 @@ def test_adam_multi_vector_path_equals_scalar_kernel():
     assert not torch.equal(outs[0][0], base[0])
 
 
-@pytest.mark.parametrize("n,players", [(1000, 2), (300, 5)])
-def test_mfma_actor_equals_library_actor(n, players):
+@pytest.mark.parametrize("n,players,game,atoms,hidden", [(1000, 2, "Hanabi-Full", 51, 512), (300, 5, "Hanabi-Full", 51, 512),
+                                                        (700, 3, "Hanabi-Small", 21, 256), (65, 2, "Hanabi-Very-Small", 64, 256)])
+def test_mfma_actor_equals_library_actor(n, players, game, atoms, hidden):
     """csrc/actor.hip (hb_actor_hidden + hb_actor_q + hb_policy_select) against cast + hipBLASLt GEMMs + hb_policy_act on
     the same agent: same hidden activations (bf16, bit for bit up to accumulation order), same actions except where
     two q values differ by rounding; ragged row counts (not a multiple of the 256-row tile) and 5-player shapes
@@ -336,10 +337,11 @@ def test_mfma_actor_equals_library_actor(n, players):
     import hanabi_hip
     from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
 
-    cfg = hanabi_hip.make_config("Hanabi-Full", players)
+    cfg = hanabi_hip.make_config(game, players)
     L = K_lib().hb_obs_len(C_byref(cfg))
     A = K_lib().hb_num_actions(C_byref(cfg))
-    params = RlaxRainbowParams(train_batch_size=32, experience_buffer_size=4096, layers=[512], compute_dtype="bfloat16")
+    params = RlaxRainbowParams(train_batch_size=32, experience_buffer_size=4096, layers=[hidden], compute_dtype="bfloat16",
+                               n_atoms=atoms)   # 51 atoms: the unrolled epilogue; other counts: the generic one
     agent = DQNAgent(ObservationSpec((n, L)), ActionSpec(A), params, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(5)
     obs = (torch.rand(n, L, device="cuda", generator=g) < 0.35).to(torch.int8)
@@ -365,8 +367,8 @@ def test_mfma_actor_equals_library_actor(n, players):
         x = torch.zeros(n, fl.Kp, dtype=torch.bfloat16, device="cuda")
         x[:, :L] = obs.to(torch.bfloat16)
         h_old = torch._addmm_activation(b1, x, w1, use_gelu=False)
-        lg = torch.addmm(b2, h_old, w2)[:, :A * 51].float().view(n, A, 51)
-        q_old = (torch.softmax(lg, -1) * agent.atoms[0]).sum(-1) / 51
+        lg = torch.addmm(b2, h_old, w2)[:, :A * atoms].float().view(n, A, atoms)
+        q_old = (torch.softmax(lg, -1) * agent.atoms[0]).sum(-1) / atoms
         assert (h_new.float() - h_old.float()).abs().max().item() <= 0.02 * h_old.float().abs().max().item()
         assert (h_new != h_old).float().mean().item() < 1e-3
         assert torch.allclose(q_new, q_old, rtol=2e-3, atol=2e-4)
