@@ -299,6 +299,24 @@ def main():
         line["roofline"]["traffic_source"] = "profiles/r01/env_kernel_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
     if session is not None:
         line["mean_episode_score"] = session.mean_score()
+        # the same kernel with the GPU to itself (random-legal policy, no agents): inside the loop it shares the chip with
+        # the learner stream's kernels, which lengthens its launches
+        sa = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+        for a, b in sa:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        for k in range(60):
+            env.set_profile_events(*sa[k])
+            env.random_legal_actions(4321, 10_000 + k, out=act)
+            env.step(act)
+        torch.cuda.synchronize()
+        env.set_profile_events(None, None)
+        alone = sorted(a.elapsed_time(b) for a, b in sa[10:])
+        alone_s = sum(alone) / len(alone) / 1e3
+        line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_per_step / alone_s / 1e9,
+                                          "frac": n * bytes_per_step / alone_s / 1e9 / HBM_PEAK_GBS,
+                                          "note": "same kernel, env-only stepping after the timed region (50 launches)"}
         line["roofline_qnet"] = qnet_roofline(agents[0], env, args)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args)

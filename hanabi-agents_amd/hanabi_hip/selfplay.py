@@ -81,11 +81,14 @@ class SelfPlaySession:
             agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
         actions = agent.explore(observations) if explore else agent.exploit(observations)
         self.last_actions[seat] = actions
+        env.step(actions)
         acted = None
         if main is not None:
+            # The policy has read the weights: the learner may overwrite them from here on. Recorded AFTER the env step:
+            # releasing the learner before it is throughput-neutral (0.194 ms either way) but makes the HBM-bound env
+            # kernel share the chip with the update's first kernels (18 us per launch instead of 14).
             acted = torch.cuda.Event()
-            acted.record(main)  # the policy has read the weights: the learner may overwrite them from here on
-        env.step(actions)
+            acted.record(main)
         self.env_steps += env.n
         if self.learner_stream is None:
             self._train_inline(agent, seat, train)
