@@ -2,7 +2,10 @@
 """bench.py — headline benchmark of the MI355X-native Hanabi self-play + Rainbow-DQN path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or started plainly: `python bench.py --gpus N` with
+    no WORLD_SIZE set starts its N ranks itself as child processes (one per GPU, RCCL over xGMI) BEFORE anything in the
+    parent touches the GPU; rank 0 prints the JSON line, a failed rank makes the parent exit non-zero.
 
 Workload (BASELINE.json configs[2]): 2-player full Hanabi, 32 768 parallel games PER GPU (weak
 scaling: games shard embarrassingly, global game ids = rank * 32768 + local), two Rainbow agents
@@ -26,6 +29,8 @@ Extra objects on the same JSON line:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -59,7 +64,59 @@ def parse():
                     help="reserve this many CUs for the learner stream (CU-masked streams); 0 = no partition")
     ap.add_argument("--no-learner-stream", action="store_true", help="run the updates in order on the main stream")
     ap.add_argument("--learner-priority", type=int, default=-1, help="HIP stream priority of the learner stream (-1 = high)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous the ranks and all-reduce one number (works without a GPU: gloo); tests the launcher")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as children. The parent never initialises
+    the GPU (no torch.cuda call happens before this point) and never re-execs; it waits, and if a rank fails it stops the
+    others (exact PIDs) and exits with that rank's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:      # one rank died: the others would hang in the next collective
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc if rc >= 0 else 1
+
+
+def launch_check(rank, world):
+    """Rendezvous + one all-reduce, no hot path: what tests/test_bench_launch.py runs on a CPU-only box."""
+    backend = os.environ.get("HB_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("HB_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "backend": backend, "sum": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def usable_cores():
@@ -96,6 +153,43 @@ def cpu_baseline(args):
             "single_thread_value": out["1"], "all_cores_value": out["all"],
             "sample": f"{n} games x {steps} lock-step moves of the same 2-player full Hanabi workload "
                       f"(oracle/hanabi_oracle.c: step + legal mask + canonical encoder, random-legal policy)"}
+
+
+def cpu_baseline_learner(args, obs_len, n_actions):
+    """grad-steps/s half of the metric on the host cores: the fp32 PyTorch-autograd restatement of
+    DQNLearning.update_q (rlax_rainbow.py:153-217: three NoisyMLP forwards, C51 double-Q cross-entropy, IS weights,
+    backward, Adam eps 3.125e-5) at B = 256 on torch-CPU — the reference's own learner is JAX and cannot run here. Uniform
+    sampling from a 4 096-row ring (the PER tree on the host is timed separately: cpu_baseline_sum_tree)."""
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    cores = usable_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        n = 4096
+        params = RlaxRainbowParams(use_priority=False, experience_buffer_size=n, mask_terminal=True, seed=7)
+        agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_actions), params, device="cpu")
+        g = torch.Generator().manual_seed(0)
+        o1 = (torch.rand(n, obs_len, generator=g) < 0.3).to(torch.int8)
+        o2 = (torch.rand(n, obs_len, generator=g) < 0.3).to(torch.int8)
+        legal = torch.ones(n, n_actions, dtype=torch.int8)
+        agent.add_experience_first((None, (o1, legal)), torch.zeros(n))
+        agent.add_experience((None, (o2, legal)), torch.randint(0, n_actions, (n,), generator=g), torch.rand(n, generator=g),
+                             torch.ones(n))
+        for _ in range(3):
+            agent.update()
+        t0 = time.perf_counter()
+        k = 0
+        while k < 400 and time.perf_counter() - t0 < 8.0:
+            agent.update()
+            k += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": k / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port", "batch": 256, "dtype": "float32",
+            "ms_per_update": dt / k * 1e3,
+            "sample": f"{k} update() calls of the torch-CPU fp32 learner (DQNLearning.loss + torch.optim.Adam, NoisyMLP "
+                      f"{obs_len}->512->{n_actions}x51, batch 256, uniform replay), torch.set_num_threads({cores})"}
 
 
 def sum_tree_baseline(device):
@@ -158,9 +252,15 @@ def sum_tree_baseline(device):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.launch_check:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        return launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
     # rehearsal knobs (one-GPU box): HB_BENCH_DEVICE pins every rank to one device, HB_DIST_BACKEND=gloo replaces RCCL,
@@ -317,9 +417,18 @@ def main():
         line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_per_step / alone_s / 1e9,
                                           "frac": n * bytes_per_step / alone_s / 1e9 / HBM_PEAK_GBS,
                                           "note": "same kernel, env-only stepping after the timed region (50 launches)"}
+        # every rank runs it (the learner update inside contains the gradient all-reduce); rank 0's numbers are printed
         line["roofline_qnet"] = qnet_roofline(agents[0], env, args)
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if rank == 0:
+            from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
+
+            if args.compute_dtype in TOLERANCE:
+                line["tolerance"] = dict(TOLERANCE[args.compute_dtype], dtype=args.compute_dtype, reference="fp32 PyTorch-autograd path "
+                                         "(DQNLearning.loss + Adam; DQNPolicy.q_values)", test="tests/test_dtype_parity.py")
+    if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
+        if not args.env_only:
+            line["cpu_baseline_learner"] = cpu_baseline_learner(args, env.obs_len, env.num_actions)
         line["cpu_baseline_sum_tree"] = sum_tree_baseline(device)
     if rank == 0:
         print(json.dumps(line), flush=True)
@@ -394,15 +503,23 @@ def qnet_roofline(agent, env, args):
     exec_flop = 2.0 * (kp * hidden + hidden * ncols)
     exec_tf = exec_flop * n / actor_s / 1e12
     learn_tf = 5.0 * 256 * fwd_flop / learn_s / 1e12
+    # learner: 3 forward passes of B rows (online on obs_tm1 and obs_t, target on obs_t; the merged layer-1 GEMM also computes
+    # the unused target half of obs_tm1) + backward (dW2, dH, dW1) on the merged weights
+    learn_exec_flop = 256 * (3 * exec_flop + 2.0 * (2 * hidden * ncols + kp * hidden))
+    learn_exec_tf = learn_exec_flop / learn_s / 1e12
+    # `achieved` / `frac` price the FLOPs the kernels EXECUTE (merged weights: one GEMM per layer); the literal two-GEMM
+    # count of SURVEY §8(d) stays beside them as algorithmic_*
     return {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "dtype": args.compute_dtype,
-            "actor_forward": {"rows": n, "algorithmic_gflop": fwd_flop * n / 1e9, "ms": actor_s * 1e3, "achieved": actor_tf,
-                              "frac": actor_tf / peak, "executed_gflop": exec_flop * n / 1e9, "executed_achieved": exec_tf,
-                              "executed_frac": exec_tf / peak,
+            "actor_forward": {"rows": n, "executed_gflop": exec_flop * n / 1e9, "ms": actor_s * 1e3, "achieved": exec_tf,
+                              "frac": exec_tf / peak, "algorithmic_gflop": fwd_flop * n / 1e9, "algorithmic_achieved": actor_tf,
+                              "algorithmic_frac": actor_tf / peak,
                               "kernels": ("hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
                                           if mfma_actor else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act"),
                               "per_kernel": per_kernel},
-            "learner_update": {"batch": 256, "algorithmic_gflop": 5.0 * 256 * fwd_flop / 1e9, "ms": learn_s * 1e3,
-                               "achieved": learn_tf, "frac": learn_tf / peak, "grad_steps_per_sec_alone": 1.0 / learn_s}}
+            "learner_update": {"batch": 256, "executed_gflop": learn_exec_flop / 1e9, "ms": learn_s * 1e3,
+                               "achieved": learn_exec_tf, "frac": learn_exec_tf / peak,
+                               "algorithmic_gflop": 5.0 * 256 * fwd_flop / 1e9, "algorithmic_achieved": learn_tf,
+                               "algorithmic_frac": learn_tf / peak, "grad_steps_per_sec_alone": 1.0 / learn_s}}
 
 
 if __name__ == "__main__":

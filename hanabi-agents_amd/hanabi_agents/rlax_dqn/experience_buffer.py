@@ -173,10 +173,18 @@ class ExperienceBuffer:
         rew = self._rew_t_buf[j, 0].clone()
         disc = torch.full_like(rew, gamma)
         alive = torch.ones_like(j, dtype=torch.bool)
-        if self.size >= cap:
-            ahead = (self.oldest_entry - 1 - indices) % cap
-        else:
-            ahead = self.size - 1 - indices
+        # Ring bounds come from the DEVICE scalars {size, write pointer}, like hb_replay_gather: inside a captured
+        # update graph host ints would be frozen at capture time and later replays would walk chains past the real
+        # write pointer. sync_size() (called by the agent before every update, outside the graph) refreshes them.
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            if not self.track_wp:
+                self.track_wp, self._synced = True, None
+            self.sync_size()
+        elif not self.track_wp:
+            raise RuntimeError("gather_nstep_dev inside a captured graph needs track_wp (set before the capture)")
+        size, wp = self._size_wp[0], self._size_wp[1]
+        ahead = torch.where(size >= cap, (wp - 1 - indices) % cap, size - 1 - indices)
         for m in range(1, n_step):
             alive = alive & ~self._terminal_t_buf[j, 0] & (m * n_ins <= ahead)
             nxt = (j + n_ins) % cap

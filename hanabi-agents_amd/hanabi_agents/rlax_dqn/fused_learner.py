@@ -96,7 +96,8 @@ class FusedLearner:
         # Single rank: Adam reads the weight gradients straight from the (padded, GEMM-dtype) outputs of the two
         # backward GEMMs and the bias gradients from the column-sum outputs: no pack / convert launches. With data
         # parallelism the gradients are first packed into the flat fp32 all-reduce bucket above.
-        self.direct = agent._dp_world() == 1
+        # (decided at the first update, when the process group the run uses is certainly up)
+        self.direct = None
         # the actor's forward on the hand-written MFMA kernels (csrc/actor.hip) reads transposed copies of eff
         from hanabi_hip.ops import ActorMFMA
 
@@ -140,6 +141,8 @@ class FusedLearner:
         """Forward, loss, backward into flat_grad. indices int64 [B], prios float64 [B] (device)."""
         a, L = self.agent, K.lib()
         buf, B = a.experience, self.B
+        if self.direct is None:
+            self.direct = a._dp_world() == 1
         if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
             raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         s = K.current_stream()

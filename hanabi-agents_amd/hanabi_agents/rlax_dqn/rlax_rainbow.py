@@ -184,6 +184,7 @@ class DQNAgent:
         self.use_mfma_actor = True   # csrc/actor.hip when the FusedLearner can feed it; False = cast + library GEMMs + hb_policy_act
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
+        self._is_max_local = self._is_max_global = None   # params.global_is_max: per-rank / all-rank IS normalisers
 
     @property
     def last_loss(self):
@@ -479,9 +480,11 @@ class DQNAgent:
                 fl.refresh_effective()
                 fl.refresh_target()
             indices, prios = self._sample_indices()
+            self._note_local_is_max(prios)
             td, _ = fl.part1(indices, prios)
             return None, indices, td  # the loss value is formed on demand (last_loss) from td and the IS weights
         indices, prios, tr = self._sample()
+        self._note_local_is_max(prios)
         if self.params.resample_noise:
             self.online.resample()
             self.target.resample()
@@ -514,13 +517,68 @@ class DQNAgent:
     def _graphs_enabled(self):
         return self.use_graphs and self.device.type == "cuda"
 
+    # ---- state touched by one update: snapshot / restore around the capture warm-up ---------------------------
+    def _learner_state_tensors(self):
+        """Every device tensor an update writes (besides scratch): weights, moments, step counters, effective weights,
+        PER running max / min. The sum tree is handled separately (its nodes are exported / imported whole)."""
+        ts = [p.data for p in self.online.parameters()] + list(self.online.buffers())
+        ts += [p.data for p in self.target.parameters()] + list(self.target.buffers())
+        fl = self._fl
+        if fl is not None:
+            seen = set()
+            for mv in fl.state.values():
+                for t in mv:
+                    if id(t) not in seen:
+                        seen.add(id(t))
+                        ts.append(t)
+            ts += [fl.step, fl.w1cat, fl.b1cat, fl.w2st, fl.b2st]
+        if self.params.use_priority:
+            ts += [self.experience._max_priority, self.experience._min_priority]
+        return ts
+
+    def _snapshot_learner_state(self):
+        snap = dict(tensors=[t.clone() for t in self._learner_state_tensors()], last_loss=self._last_loss,
+                    rng=torch.cuda.get_rng_state(self.device), gen=self._gen.get_state())
+        if self.params.use_priority:
+            snap["tree"] = self.experience.sum_tree.nodes().clone()
+        if self._fl is None:
+            # torch.optim.Adam creates its state lazily: remember what existed (nothing before the first step)
+            snap["adam"] = {id(p): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                            for p, st in self.optimizer.state.items()}
+        return snap
+
+    def _restore_learner_state(self, snap):
+        with torch.no_grad():
+            for dst, src in zip(self._learner_state_tensors(), snap["tensors"]):
+                dst.copy_(src)
+            if "tree" in snap:
+                self.experience.sum_tree.import_nodes(snap["tree"])
+            if "adam" in snap:
+                for p, st in self.optimizer.state.items():
+                    old = snap["adam"].get(id(p))
+                    for k, v in st.items():
+                        if isinstance(v, torch.Tensor):  # in place: the captured graph holds these tensors
+                            v.zero_() if old is None else v.copy_(old[k])
+        torch.cuda.set_rng_state(snap["rng"], self.device)
+        self._gen.set_state(snap["gen"])
+        self._last_loss = snap["last_loss"]
+        self._eff_cache = None
+        if self._fl is not None:
+            self._fl.actor_stale = True
+
     def _capture_update_graphs(self):
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, cuBLAS-like workspaces, Adam state)
+        # Warm-up off the capture stream (allocator, GEMM workspaces, lazily created Adam state). The warm-up updates are
+        # real updates, so everything they write is put back afterwards: update() stays exactly ONE gradient step, as
+        # in the reference (rlax_rainbow.py:310-339), whether or not graphs are in use.
+        self._fused_learner()
+        with torch.cuda.stream(side):
+            snap = self._snapshot_learner_state()
             for _ in range(3):
                 self._update_eager()
+            self._restore_learner_state(snap)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -545,14 +603,40 @@ class DQNAgent:
             return 1
         return dist.get_world_size(self.process_group)
 
+    def _note_local_is_max(self, prios):
+        """global_is_max: remember this rank's max_i (1/P_i)^beta (the normaliser its loss used) for the rescale below."""
+        if self.params.global_is_max and self._dp_world() > 1:
+            if self._is_max_local is None:
+                self._is_max_local = torch.ones(1, dtype=torch.float32, device=self.device)
+                self._is_max_global = torch.ones(1, dtype=torch.float32, device=self.device)
+            self._is_max_local.copy_(((1.0 / prios).to(torch.float32) ** self._beta).max().reshape(1))
+
     def _allreduce_gradients(self, async_op=False):
         """Data parallelism: ONE all-reduce (sum) of the flat fp32 gradient over RCCL. Returns the
-        torch.distributed Work handle when async_op (None with a single rank)."""
+        torch.distributed Work handle when async_op (None with a single rank).
+
+        With params.global_is_max the gradient is first rescaled from the per-rank IS normaliser to the global one:
+        w_i / max_rank(w) = (w_i / max_all(w)) * (max_all / max_rank)  =>  g_global = g_rank * max_rank / max_all,
+        max_all from one 4-byte all-reduce(MAX) — the reference's single-batch `w /= max(w)` (rlax_rainbow.py:188-189)
+        over the global batch, exactly."""
         import torch.distributed as dist
 
-        if self._dp_world() == 1:
+        world = self._dp_world()
+        if self._fl is not None and self._fl.direct is not None and self._fl.direct != (world == 1):
+            raise RuntimeError("the process group changed after the FusedLearner was built: its gradient routing "
+                               "(direct GEMM outputs vs packed all-reduce bucket) no longer matches the world size")
+        if world == 1:
             return None
         flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
+        if self.params.global_is_max:
+            self._is_max_global.copy_(self._is_max_local)
+            dist.all_reduce(self._is_max_global, op=dist.ReduceOp.MAX, group=self.process_group)
+            scale = self._is_max_local / self._is_max_global
+            flat.mul_(scale)
+            if self._fl is not None:
+                self._fl.w_is.mul_(scale)   # last_loss = mean(td * w_IS) reports the globally normalised weights
+            elif self._last_loss is not None:
+                self._last_loss = self._last_loss * scale[0]
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         if not async_op:
             work.wait()

@@ -1,0 +1,38 @@
+"""bench.py's own launcher (CPU box, gloo): `python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its two
+ranks itself, they rendezvous on 127.0.0.1 and all-reduce; a failing rank makes the parent exit non-zero instead of hanging."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env=None, args=("--gpus", "2", "--launch-check")):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HB_DIST_BACKEND="gloo", **(extra_env or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_starts_its_own_ranks():
+    r = _run()
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out == {"launch_check": True, "world": 2, "backend": "gloo", "sum": 3.0}
+
+
+def test_bench_failed_rank_gives_nonzero_exit():
+    r = _run({"HB_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_under_a_launcher_keeps_its_world():
+    """Started with WORLD_SIZE already set (torch.distributed.run does that), bench.py must NOT spawn again."""
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29999"}
+    r = _run(env, args=("--gpus", "1", "--launch-check"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["world"] == 1

@@ -74,6 +74,66 @@ def test_gradient_allreduce_keeps_ranks_identical(tmp_path):
     assert np.allclose(r[0]["weights"].numpy(), want, atol=1e-6)
 
 
+def _is_max_worker(rank, world, port, out):
+    """params.global_is_max: each rank holds 8 transitions with ITS OWN sampling probabilities; the applied gradient must
+    be the one a single process computes on the 16-row global batch with w /= max over all 16 (rlax_rainbow.py:188-189)."""
+    for p in (ROOT, os.path.join(ROOT, "hanabi-agents_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, DQNLearning, ObservationSpec, RlaxRainbowParams
+    from hanabi_agents.rlax_dqn import learning as L
+
+    n, obs_len, n_act = 8, 24, 4
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=8, experience_buffer_size=8, layers=[8], n_atoms=5,
+                               atom_vmax=2, seed=5, global_is_max=True)
+    agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cpu")
+    data = []
+    for r in range(world):   # every rank builds both shards: its own to train on, all of them for the single-process reference
+        rng = np.random.default_rng(100 + r)
+        o1, o2 = (rng.integers(0, 2, (n, obs_len)).astype(np.int8) for _ in range(2))
+        data.append((o1, o2, rng.integers(0, n_act, n), rng.integers(0, 2, n).astype(float), (rng.random(n) + 0.05) / (1 + 3 * r)))
+    o1, o2, act, rew, pri = data[rank]
+    legal = np.ones((n, n_act), np.int8)
+    agent.add_experience_first((None, (o1, legal)), np.zeros(n))
+    agent.add_experience((None, (o2, legal)), act, rew, np.ones(n))
+    agent._sample_indices = lambda: (torch.arange(n), torch.as_tensor(pri))
+    # single-process reference on the global batch: w = (1/P)^beta / max over ALL rows; mean over 16 rows
+    w_all = torch.cat([(1.0 / torch.as_tensor(d[4])).float() ** 0.4 for d in data])
+    w_all = w_all / w_all.max()
+    total = 0.0
+    for r, d in enumerate(data):
+        from hanabi_agents.rlax_dqn.transition import Transition
+
+        tr = Transition(torch.as_tensor(d[0]).float(), torch.as_tensor(d[2])[:, None], torch.as_tensor(d[3])[:, None].float(),
+                        torch.as_tensor(d[1]).float(), torch.ones(n, n_act), torch.zeros(n, 1, dtype=torch.bool))
+        a, k = agent.atoms.shape
+        td = L.categorical_double_q_td(agent.online(tr.observation_tm1).view(-1, a, k), tr.action_tm1[:, 0].long(),
+                                       tr.reward_t[:, 0], 0.99, agent.atoms, agent.target(tr.observation_t).view(-1, a, k),
+                                       agent.online(tr.observation_t).view(-1, a, k).detach())
+        total = total + torch.sum(td * w_all[r * n:(r + 1) * n])
+    g_ref = torch.cat([x.reshape(-1) for x in torch.autograd.grad(total / (world * n), list(agent.online.parameters()))])
+    agent.experience.sync_size()
+    agent._beta.fill_(0.4)
+    agent._update_part1()
+    agent._finish_allreduce(agent._allreduce_gradients(async_op=False))
+    torch.save({"grad": agent._flat_grad.clone(), "ref": g_ref, "scale": (agent._is_max_local / agent._is_max_global).clone()},
+               os.path.join(out, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_is_weight_normalisation_matches_single_global_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_is_max_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"m{i}.pt") for i in range(world)]
+    assert torch.equal(r[0]["grad"], r[1]["grad"])
+    assert torch.allclose(r[0]["grad"], r[0]["ref"], rtol=1e-4, atol=1e-7)
+    scales = sorted(float(x["scale"]) for x in r)
+    assert scales[1] == 1.0 and scales[0] < 0.9     # one rank held the global max, the other was rescaled
+
+
 def test_rank_shards_use_disjoint_reproducible_decks():
     """Games are sharded by global id: rank r owns [r*N, (r+1)*N). The decks a rank deals are exactly the slice
     a single process would deal for those ids (checked on the oracle; the HIP side is compared to the oracle with

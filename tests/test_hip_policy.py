@@ -145,16 +145,58 @@ def test_graphed_update_equals_eager_update():
         a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
         a.add_experience((None, (o2, legal)), act, rew, torch.ones(n, dtype=torch.int8, device="cuda"))
         a.experience.sample_indices_dev = lambda b: torch.arange(b, device="cuda")   # same batch, fixed order
-    for _ in range(3):       # the graphed agent spends 3 warm-up updates (no target sync) at capture time: same here
-        agents[1].experience.sync_size()
-        agents[1]._update_eager()
-    for step in range(6):
+    for step in range(6):    # (the capture's warm-up updates are rolled back: update() is exactly one gradient step either way)
         for a in agents:
             a.update()
     w = [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]) for a in agents]
     assert torch.allclose(w[0], w[1], rtol=1e-4, atol=1e-6)
     assert agents[0]._graph1 is not None and agents[1]._graph1 is None
     assert torch.allclose(agents[0].last_loss, agents[1].last_loss, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_nstep_update_follows_the_ring_after_capture(fused):
+    """HIP graphs + n_step > 1: the n-step chain walk must read the ring's size / write pointer from device scalars, not
+    from host ints frozen at capture time. Graphed and eager agents see the same inserts BETWEEN updates (so the ring
+    advances after the capture) and must stay equal — non-fused (torch gather_nstep_dev) and fused (hb_replay_gather)."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    n, obs_len, n_act = 64, 658, 20
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=64, experience_buffer_size=64 * 7, target_update_period=4,
+                               n_step=3, mask_terminal=True)
+    agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=g,
+                       use_fused_learner=fused) for g in (True, False)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
+
+    def insert(first=False):
+        obs = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+        act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+        rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
+        st = (torch.rand(n, device="cuda", generator=g) < 0.15).to(torch.int8) + 1
+        for a in agents:
+            if first:
+                a.add_experience_first((None, (obs, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+            else:
+                a.add_experience_dense((None, (obs, legal)), act, rew, st)
+
+    insert(first=True)
+    insert()
+    insert()
+    pick = [torch.randint(0, 10 ** 6, (64,), device="cuda", generator=g) for _ in range(12)]
+    cur = torch.zeros(64, dtype=torch.int64, device="cuda")   # persistent: the captured graph reads it by address
+    for a in agents:   # same sampled rows for both agents, drawn from the ring as it is NOW (device size scalar)
+        a.experience.sample_indices_dev = lambda b, a=a: cur % a.experience._size_t.long()
+    for step in range(12):
+        cur.copy_(pick[step])
+        for a in agents:
+            a.update()
+        insert()      # the ring grows, then wraps (capacity 7 inserts), while the captured graph keeps replaying
+    assert agents[0]._graph1 is not None and agents[1]._graph1 is None
+    w = [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]) for a in agents]
+    assert torch.allclose(w[0], w[1], rtol=1e-4, atol=1e-6)
 
 
 def test_batched_gpu_loss_equals_reference_loss_and_gradient():
@@ -281,8 +323,8 @@ def test_relu_backward_with_column_sums_and_update_counter():
                      torch.ones(n, dtype=torch.int8, device="cuda"))
     for _ in range(4):
         a.update()
-    warm = 3  # eager warm-up updates run by the graph capture (rlax_rainbow.py: _capture_update_graphs)
-    assert a._fl.step.item() == 4 + warm and a.train_step == 4
+    # (the graph capture's eager warm-up updates are rolled back: rlax_rainbow.py _capture_update_graphs)
+    assert a._fl.step.item() == 4 and a.train_step == 4
 
 
 def test_adam_multi_vector_path_equals_scalar_kernel():
