@@ -50,10 +50,11 @@ constexpr int OUT_LD = 520;                       // bytes per row of the bf16 o
 constexpr int LDS_BYTES = BM * OUT_LD > 2 * STAGE ? BM * OUT_LD : 2 * STAGE;  // 133 120
 
 struct GemmArgs {
-  const void* x;        // activations: int8 [M, x_ld] (MODE 0) or bf16 [M, x_ld] (MODE 1)
+  const void* x;        // activations: int8 [M, x_ld] (MODE 0), bf16 [M, x_ld] (MODE 1), bit-packed rows of x_ld BYTES (MODE 2)
   long long m;
   int x_ld;             // row stride in ELEMENTS
-  int k_real;           // valid K of the activations (columns >= k_real read as 0); k_pad = multiple of 64 >= k_real
+  int k_real;           // valid K of the activations (columns >= k_real read as 0; MODE 2: the row's bit count, 32 * words);
+                        // k_pad = multiple of 64 >= k_real
   int k_pad;
   const __hip_bfloat16* wt;  // weights transposed: [n_rows_total][k_pad]
   const float* bias;         // [n_rows_total]
@@ -114,6 +115,14 @@ __device__ __forceinline__ float c51_expectation(const uint2* __restrict__ p8, c
   return t / s / static_cast<float>(KK);
 }
 
+// eight observation bits -> eight bf16 0.0 / 1.0 (0x3F80): two bits per dword, spread to bits 0 and 16, times 0x3F80
+__device__ __forceinline__ uint32_t bits2_bf16(uint32_t b, int p) {
+  const uint32_t t = (b >> (2 * p)) & 3u;
+  return __umul24((t | (t << 15)) & 0x00010001u, 0x3F80u);
+}
+
+// MODE 0: hidden layer from int8 observations; MODE 1: output layer + C51 expectation; MODE 2: hidden layer from bit-packed
+// observations (8x fewer bytes per row; a lane's 8 k-values are ONE byte of the row)
 template <int MODE>
 __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -147,6 +156,9 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
           }                                                                                                         \
       }                                                                                                             \
       XR = make_uint4(d0, d1, 0u, 0u); /* widened when it is written to LDS, after the MFMAs of this step */         \
+    } else if (MODE == 2) {                                                                                         \
+      const uint8_t* p = static_cast<const uint8_t*>(a.x) + row * a.x_ld + (k >> 3);                                \
+      XR = make_uint4(k < a.k_real ? static_cast<uint32_t>(*p) : 0u, 0u, 0u, 0u);                                    \
     } else {                                                                                                        \
       XR = *reinterpret_cast<const uint4*>(static_cast<const __hip_bfloat16*>(a.x) + row * a.x_ld + k);            \
     }                                                                                                               \
@@ -169,6 +181,9 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
       widen4(XR.x, e0, e1);                                                      \
       widen4(XR.y, e2, e3);                                                      \
       *reinterpret_cast<uint4*>(base_ + off) = make_uint4(e0, e1, e2, e3);       \
+    } else if (MODE == 2) {                                                      \
+      *reinterpret_cast<uint4*>(base_ + off) =                                   \
+          make_uint4(bits2_bf16(XR.x, 0), bits2_bf16(XR.x, 1), bits2_bf16(XR.x, 2), bits2_bf16(XR.x, 3)); \
     } else {                                                                     \
       *reinterpret_cast<uint4*>(base_ + off) = XR;                               \
     }                                                                            \
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       float v0 = acc[n][m][0] + b.x, v1 = acc[n][m][1] + b.y, v2 = acc[n][m][2] + b.z, v3 = acc[n][m][3] + b.w;
-      if (MODE == 0) {
+      if (MODE != 1) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       }
       const int rl = wr * 128 + m * 16 + (lane & 15);
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
 #undef HB_STORE_ONE
 #undef HB_STORE_STAGE
   __syncthreads();
-  if (MODE == 0) {
+  if (MODE != 1) {
     // coalesced copy-out: 32 chunks of 16 bytes per row
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
@@ -415,6 +430,24 @@ int hb_actor_hidden(const int8_t* obs_dev, int64_t n_rows, int32_t obs_len, cons
   a.h = static_cast<__hip_bfloat16*>(h_dev); a.h_ld = hidden;
   const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(hidden / BN));
   hipLaunchKernelGGL((actor_gemm_kernel<0>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_actor_hidden_packed(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev, int32_t k_pad,
+                           const float* b1_dev, int32_t hidden, void* h_dev, void* stream) {
+  if (!obs_bits_dev || !w1t_dev || !b1_dev || !h_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_rows <= 0) return HB_OK;
+  if (obs_len < 1 || k_pad < obs_len || k_pad % BK) return fail(HB_ERR_INVALID, "k_pad must be a multiple of 64 and >= obs_len");
+  if (hidden < BN || hidden % BN) return fail(HB_ERR_INVALID, "hidden must be a multiple of 256");
+  if (!aligned16(w1t_dev) || !aligned16(b1_dev) || !aligned16(h_dev)) return fail(HB_ERR_ALIGN, "w1t / b1 / h must be 16-byte aligned");
+  const int words = (obs_len + 31) / 32;
+  GemmArgs a{};
+  a.x = obs_bits_dev; a.m = n_rows; a.x_ld = words * 4; a.k_real = words * 32; a.k_pad = k_pad;
+  a.wt = static_cast<const __hip_bfloat16*>(w1t_dev); a.bias = b1_dev;
+  a.h = static_cast<__hip_bfloat16*>(h_dev); a.h_ld = hidden;
+  const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(hidden / BN));
+  hipLaunchKernelGGL((actor_gemm_kernel<2>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

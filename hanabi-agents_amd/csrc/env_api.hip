@@ -101,6 +101,7 @@ int hb_obs_len(const hb_config* c) {
          (P + 4 + P + c->colors + c->ranks + H + H + bits + 2) + P * H * (bits + c->colors + c->ranks);
 }
 int hb_state_words(const hb_config* c) { return c->players <= 3 ? 32 : 48; }
+int hb_obs_words(const hb_config* c) { return (hb_obs_len(c) + 31) / 32; }
 
 int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t first_game_id, hb_env** out) {
   if (!out) return fail(HB_ERR_INVALID, "null out");
@@ -256,6 +257,12 @@ static int check_out(const void* obs, const void* legal) {
     return fail(HB_ERR_ALIGN, "obs_dev / legal_dev must be 16-byte aligned");
   return HB_OK;
 }
+static int check_out_packed(const void* bits, const void* obs, const void* legal) {
+  if (!bits || !legal) return fail(HB_ERR_INVALID, "obs_bits_dev and legal_dev are required");
+  if ((reinterpret_cast<uintptr_t>(bits) & 15) || (reinterpret_cast<uintptr_t>(legal) & 15) || (reinterpret_cast<uintptr_t>(obs) & 15))
+    return fail(HB_ERR_ALIGN, "obs_bits_dev / obs_dev / legal_dev must be 16-byte aligned");
+  return HB_OK;
+}
 
 int hb_env_reset(hb_env* e, const uint8_t* mask_dev, int32_t start_player, void* stream) {
   if (!e) return fail(HB_ERR_INVALID, "null env");
@@ -302,6 +309,42 @@ int hb_env_step(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* 
   if (int rc = join_refill(e, stream)) return rc;
   if (int rc = launch(e, a, stream)) return rc;
   return refill_async(e, stream);  // re-shuffle the pool entries this step consumed, off the caller's stream
+}
+
+int hb_env_observe_packed(hb_env* e, uint32_t* obs_bits_dev, int8_t* obs_dev, int8_t* legal_dev, float* agent_reward_dev,
+                          int8_t* agent_step_type_dev, void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (int rc = check_out_packed(obs_bits_dev, obs_dev, legal_dev)) return rc;
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_OBSERVE;
+  a.obs = obs_dev;
+  a.obs_bits = obs_bits_dev;
+  a.legal = legal_dev;
+  a.agent_reward = agent_reward_dev;
+  a.agent_step_type = agent_step_type_dev;
+  return launch(e, a, stream);
+}
+
+int hb_env_step_packed(hb_env* e, const int32_t* actions_dev, uint32_t* obs_bits_dev, int8_t* obs_dev, int8_t* legal_dev,
+                       float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev,
+                       int8_t* score_dev, void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (!actions_dev) return fail(HB_ERR_INVALID, "actions_dev is required");
+  if (int rc = check_out_packed(obs_bits_dev, obs_dev, legal_dev)) return rc;
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_STEP;
+  a.actions = actions_dev;
+  a.obs = obs_dev;
+  a.obs_bits = obs_bits_dev;
+  a.legal = legal_dev;
+  a.reward = reward_dev;
+  a.terminal = terminal_dev;
+  a.agent_reward = agent_reward_dev;
+  a.agent_step_type = agent_step_type_dev;
+  a.score = score_dev;
+  if (int rc = join_refill(e, stream)) return rc;
+  if (int rc = launch(e, a, stream)) return rc;
+  return refill_async(e, stream);
 }
 
 #ifdef HB_STAMPS

@@ -41,7 +41,8 @@ struct EnvArgs {
   const uint8_t* decks;
   uint8_t* next_deck;  // [n, 64]: the deck game g will be dealt at its next (re)deal, produced by refill_kernel
   uint8_t* refill;     // [n]: 1 = next_deck[g] was consumed (or is stale) and must be regenerated
-  int8_t* obs;
+  int8_t* obs;          // [n, OBS_LEN] int8 0/1 (the reference's layout), or NULL when only the packed form is wanted
+  uint32_t* obs_bits;   // [n, NW] u32, bit i of the observation = word i >> 5, bit i & 31 (pad bits zero), or NULL
   int8_t* legal;
   float* reward;
   int8_t* terminal;
@@ -655,7 +656,15 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   }
   HB_STAMP(8);
   if (mode != MODE_RESET) {
-    expand_rows<K::OBS_LEN>(obits, K::NWP, nvalid, a.obs + g0 * K::OBS_LEN, lane);
+    if (a.obs_bits) {
+      // packed form: the wave's nvalid x NW words are one contiguous span of HBM (rows are NW words, no padding)
+      uint32_t* dst = a.obs_bits + g0 * K::NW;
+      for (int e = lane; e < nvalid * K::NW; e += 64) {
+        const int g = e / K::NW, i = e - g * K::NW;
+        dst[e] = obits[g * K::NWP + i];
+      }
+    }
+    if (a.obs) expand_rows<K::OBS_LEN>(obits, K::NWP, nvalid, a.obs + g0 * K::OBS_LEN, lane);
     expand_rows<K::A>(lbits, K::LW, nvalid, a.legal + g0 * K::A, lane);
   }
   HB_STAMP(9);

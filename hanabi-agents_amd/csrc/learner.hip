@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const int8_t* __restrict__ 
                                                      const uint8_t* __restrict__ ring_term, const int64_t* __restrict__ idx,
                                                      int B, int L, T* __restrict__ x, int x_ld, int32_t* __restrict__ act,
                                                      float* __restrict__ rew, float* __restrict__ term,
-                                                     float* __restrict__ disc, const NStep ns) {
+                                                     float* __restrict__ disc, const NStep ns, int packed_words) {
   __shared__ long long s_slot;
   const int r = blockIdx.x;  // output row 0..2B-1
   const int b = r < B ? r : r - B;
@@ -94,8 +94,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const int8_t* __restrict__ 
   } else if (threadIdx.x == 0) {
     act[b] = ring_act[slot];
   }
-  const int8_t* src = (r < B ? ring_tm1 : ring_t) + slot * L;
   T* dst = x + static_cast<long long>(r) * x_ld;  // row stride x_ld >= L: padding columns are left untouched (zero)
+  if (packed_words > 0) {  // bit-packed rings: rows of packed_words u32, observation bit j = word j >> 5, bit j & 31
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(r < B ? ring_tm1 : ring_t) + slot * packed_words;
+    for (int j = threadIdx.x; j < L; j += 256) st<T>(dst, j, static_cast<float>((src[j >> 5] >> (j & 31)) & 1u));
+    return;
+  }
+  const int8_t* src = (r < B ? ring_tm1 : ring_t) + slot * L;
   for (int j = threadIdx.x; j < L; j += 256) st<T>(dst, j, static_cast<float>(src[j]));
 }
 
@@ -428,11 +433,11 @@ void launch_adam(const AdamArgs& a, hipStream_t s) {
 
 extern "C" {
 
-int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
+static int replay_gather_impl(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
                      const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
                      int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
                      float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert,
-                     const int64_t* size_wp_dev, void* stream) {
+                     const int64_t* size_wp_dev, void* stream, int packed_words) {
   if (!ring_obs_tm1_dev || !ring_obs_t_dev || !ring_act_dev || !ring_rew_dev || !ring_term_dev || !idx_dev || !x_dev ||
       !act_dev || !rew_dev || !term_dev || !disc_dev)
     return fail(HB_ERR_INVALID, "null argument");
@@ -446,15 +451,37 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
   const dim3 grid(static_cast<unsigned>(2 * batch)), block(256);
   const int B = static_cast<int>(batch);
   if (x_dtype == 0)
-    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
+    hipLaunchKernelGGL((gather_kernel<float>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<float*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns, packed_words);
   else if (x_dtype == 1)
-    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
+    hipLaunchKernelGGL((gather_kernel<__hip_bfloat16>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__hip_bfloat16*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns, packed_words);
   else if (x_dtype == 2)
-    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns);
+    hipLaunchKernelGGL((gather_kernel<__half>), grid, block, 0, s, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, B, obs_len, static_cast<__half*>(x_dev), x_ld, act_dev, rew_dev, term_dev, disc_dev, ns, packed_words);
   else
     return fail(HB_ERR_INVALID, "x_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
   return HB_OK;
+}
+
+int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_dev, const int8_t* ring_act_dev,
+                     const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
+                     int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
+                     float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert,
+                     const int64_t* size_wp_dev, void* stream) {
+  return replay_gather_impl(ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, batch, obs_len,
+                            x_dev, x_dtype, x_ld, act_dev, rew_dev, term_dev, disc_dev, n_step, gamma, capacity, rows_per_insert,
+                            size_wp_dev, stream, 0);
+}
+
+int hb_replay_gather_packed(const uint32_t* ring_bits_tm1_dev, const uint32_t* ring_bits_t_dev, const int8_t* ring_act_dev,
+                            const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
+                            int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
+                            float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity,
+                            int64_t rows_per_insert, const int64_t* size_wp_dev, void* stream) {
+  if (obs_len < 1) return fail(HB_ERR_INVALID, "obs_len must be positive");
+  return replay_gather_impl(reinterpret_cast<const int8_t*>(ring_bits_tm1_dev), reinterpret_cast<const int8_t*>(ring_bits_t_dev),
+                            ring_act_dev, ring_rew_dev, ring_term_dev, idx_dev, batch, obs_len, x_dev, x_dtype, x_ld, act_dev,
+                            rew_dev, term_dev, disc_dev, n_step, gamma, capacity, rows_per_insert, size_wp_dev, stream,
+                            (obs_len + 31) / 32);
 }
 
 int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,

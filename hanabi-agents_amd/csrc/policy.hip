@@ -263,9 +263,73 @@ __global__ __launch_bounds__(256) void obs_cast_kernel(const int8_t* __restrict_
     }
 }
 
+// ---- bit-packed observations <-> the reference's int8 0/1 layout -------------------------------------------------------
+// packed row = ceil(L / 32) u32 words, observation bit i = word i >> 5, bit i & 31; pad bits are zero.
+// pack: a wavefront takes 64 consecutive bytes of one row (coalesced 1-byte loads) and ballots them into two words.
+__global__ __launch_bounds__(256) void obs_pack_kernel(const int8_t* __restrict__ obs, uint32_t* __restrict__ bits, long long rows,
+                                                       int L, int W) {
+  const int lane = threadIdx.x & 63;
+  const int cpr = (L + 63) >> 6;                                            // 64-byte chunks per row
+  const long long chunk = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (chunk >= rows * cpr) return;
+  const long long r = chunk / cpr;
+  const int c = static_cast<int>(chunk - r * cpr), col = c * 64 + lane;
+  const unsigned long long m = __ballot(col < L && obs[r * L + col] != 0);
+  if (lane == 0) {
+    bits[r * W + 2 * c] = static_cast<uint32_t>(m);
+    if (2 * c + 1 < W) bits[r * W + 2 * c + 1] = static_cast<uint32_t>(m >> 32);
+  }
+}
+// unpack: thread -> (row, 16-column chunk): 16 bits -> one byte-aligned 16-byte store (4 bits -> 4 bytes per multiply,
+// the expansion of hb::expand_rows in the env kernel); the L % 16 tail bytewise
+__global__ __launch_bounds__(256) void obs_unpack_kernel(const uint32_t* __restrict__ bits, int8_t* __restrict__ obs, long long rows,
+                                                         int L, int W) {
+  const int cpr = (L + 15) >> 4;
+  const long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (id >= rows * cpr) return;
+  const long long r = id / cpr;
+  const int c = static_cast<int>(id - r * cpr);
+  const uint32_t v = (bits[r * W + (c >> 1)] >> ((c & 1) * 16)) & 0xFFFFu;
+  int8_t* dst = obs + r * L + 16 * c;
+  if (16 * c + 16 <= L) {
+    u32x4 o;
+    o.x = hb::spread4(v);
+    o.y = hb::spread4(v >> 4);
+    o.z = hb::spread4(v >> 8);
+    o.w = hb::spread4(v >> 12);
+    *reinterpret_cast<u32x4_u*>(dst) = o;
+  } else {
+    for (int j = 0; 16 * c + j < L; ++j) dst[j] = static_cast<int8_t>((v >> j) & 1u);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hb_obs_pack(const int8_t* obs_dev, uint32_t* bits_dev, int64_t rows, int32_t obs_len, void* stream) {
+  if (!obs_dev || !bits_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (rows <= 0) return HB_OK;
+  if (obs_len < 1) return fail(HB_ERR_INVALID, "obs_len must be positive");
+  const int W = (obs_len + 31) / 32;
+  const long long waves = rows * ((obs_len + 63) / 64);
+  hipLaunchKernelGGL(obs_pack_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     obs_dev, bits_dev, static_cast<long long>(rows), obs_len, W);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_obs_unpack(const uint32_t* bits_dev, int8_t* obs_dev, int64_t rows, int32_t obs_len, void* stream) {
+  if (!obs_dev || !bits_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (rows <= 0) return HB_OK;
+  if (obs_len < 1) return fail(HB_ERR_INVALID, "obs_len must be positive");
+  const int W = (obs_len + 31) / 32;
+  const long long threads = rows * ((obs_len + 15) / 16);
+  hipLaunchKernelGGL(obs_unpack_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), bits_dev, obs_dev, static_cast<long long>(rows), obs_len, W);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
 
 int hb_obs_cast(const int8_t* obs_dev, void* out_dev, int32_t out_dtype, int64_t rows, int32_t cols, int32_t out_ld,
                 void* stream) {

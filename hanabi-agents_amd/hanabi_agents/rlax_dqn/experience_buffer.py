@@ -15,6 +15,7 @@ reference's slice assignments, so ring contents are comparable entry by entry.
 import numpy as np
 import torch
 
+from . import bitpack
 from .transition import Transition
 
 
@@ -27,13 +28,19 @@ def _dev(x, device, dtype):
 class ExperienceBuffer:
     """ExperienceBuffer stores transitions for training (device-resident)."""
 
-    def __init__(self, observation_len: int, action_len: int, reward_len: int, capacity: int, device=None, seed=0):
+    def __init__(self, observation_len: int, action_len: int, reward_len: int, capacity: int, device=None, seed=0,
+                 packed=False):
         self.device = torch.device(device) if device is not None else torch.device(
             "cuda" if torch.cuda.is_available() else "cpu")
         d = self.device
-        self._obs_tm1_buf = torch.zeros((capacity, observation_len), dtype=torch.int8, device=d)
+        # packed=True: both observation rings hold bit-packed rows (bitpack.py: ceil(obs_len / 32) int32 words, 84 instead of
+        # 658 bytes for 2-player full Hanabi); everything handed OUT (`buf[indices]`, gather_dev) is the reference's int8 form
+        self.packed = bool(packed)
+        self.observation_len = int(observation_len)
+        row, odt = (bitpack.words_for(observation_len), torch.int32) if self.packed else (observation_len, torch.int8)
+        self._obs_tm1_buf = torch.zeros((capacity, row), dtype=odt, device=d)
         self._act_tm1_buf = torch.zeros((capacity, 1), dtype=torch.int8, device=d)
-        self._obs_t_buf = torch.zeros((capacity, observation_len), dtype=torch.int8, device=d)
+        self._obs_t_buf = torch.zeros((capacity, row), dtype=odt, device=d)
         self._lms_t_buf = torch.zeros((capacity, action_len), dtype=torch.int8, device=d)
         self._rew_t_buf = torch.zeros((capacity, reward_len), dtype=torch.float32, device=d)
         self._terminal_t_buf = torch.zeros((capacity, 1), dtype=torch.bool, device=d)
@@ -80,10 +87,10 @@ class ExperienceBuffer:
         """Append a batch (numpy arrays or torch tensors on any device); shapes as in the reference."""
         d = self.device
         cols = (
-            (self._obs_tm1_buf, _dev(observation_tm1, d, torch.int8)),
+            (self._obs_tm1_buf, self.obs_rows(observation_tm1)),
             (self._act_tm1_buf, _dev(action_tm1, d, torch.int8).reshape(-1, 1)),
             (self._rew_t_buf, _dev(reward_t, d, torch.float32).reshape(-1, self._rew_t_buf.shape[1])),
-            (self._obs_t_buf, _dev(observation_t, d, torch.int8)),
+            (self._obs_t_buf, self.obs_rows(observation_t)),
             (self._lms_t_buf, _dev(legal_moves_t, d, torch.int8)),
             (self._terminal_t_buf, _dev(terminal_t, d, torch.bool).reshape(-1, 1)),
         )
@@ -96,12 +103,23 @@ class ExperienceBuffer:
             for buf, val in cols:
                 buf[dst] = val[src]
 
+    def obs_rows(self, obs):
+        """Observations in this ring's storage form: int8 [n, obs_len], or packed int32 [n, words]. Accepts either form."""
+        if isinstance(obs, torch.Tensor) and bitpack.is_packed(obs, self.observation_len) and self.observation_len != obs.shape[1]:
+            obs = obs.to(self.device)
+            return obs if self.packed else bitpack.unpack(obs, self.observation_len)
+        obs = _dev(obs, self.device, torch.int8)
+        return bitpack.pack(obs) if self.packed else obs
+
+    def _obs_out(self, rows):
+        return bitpack.unpack(rows, self.observation_len) if self.packed else rows
+
     # ---- checkpointing (SURVEY §8(f)-4: the reference saves network parameters only) ---------------------
     _DATA = ("_obs_tm1_buf", "_act_tm1_buf", "_obs_t_buf", "_lms_t_buf", "_rew_t_buf", "_terminal_t_buf")
 
     def state_dict(self, include_data=True):
         """Ring pointers, sampler RNG and (optionally) the `size` rows written so far, as host tensors."""
-        sd = dict(capacity=self.capacity, oldest_entry=self.oldest_entry, size=self.size,
+        sd = dict(capacity=self.capacity, oldest_entry=self.oldest_entry, size=self.size, packed=self.packed,
                   rows_per_insert=self.rows_per_insert, gen=self._gen.get_state().cpu(), has_data=bool(include_data))
         if include_data:
             sd["data"] = {name: getattr(self, name)[:self.size].cpu() for name in self._DATA}
@@ -111,6 +129,8 @@ class ExperienceBuffer:
         """In place (captured graphs keep pointing at the same buffers)."""
         if sd["capacity"] != self.capacity:
             raise ValueError(f"checkpoint ring capacity {sd['capacity']} != {self.capacity}")
+        if bool(sd.get("packed", False)) != self.packed:
+            raise ValueError("checkpoint ring and this ring differ in observation storage (packed_obs)")
         if sd["has_data"]:
             for name in self._DATA:
                 rows = sd["data"][name]
@@ -126,8 +146,8 @@ class ExperienceBuffer:
     def gather_dev(self, indices: torch.Tensor) -> Transition:
         """Batch as device tensors (the learner's path)."""
         return Transition(
-            self._obs_tm1_buf.index_select(0, indices), self._act_tm1_buf.index_select(0, indices),
-            self._rew_t_buf.index_select(0, indices), self._obs_t_buf.index_select(0, indices),
+            self._obs_out(self._obs_tm1_buf.index_select(0, indices)), self._act_tm1_buf.index_select(0, indices),
+            self._rew_t_buf.index_select(0, indices), self._obs_out(self._obs_t_buf.index_select(0, indices)),
             self._lms_t_buf.index_select(0, indices), self._terminal_t_buf.index_select(0, indices))
 
     def __getitem__(self, indices) -> Transition:
@@ -191,8 +211,8 @@ class ExperienceBuffer:
             j = torch.where(alive, nxt, j)
             rew = torch.where(alive, rew + disc * self._rew_t_buf[j, 0], rew)
             disc = torch.where(alive, disc * gamma, disc)
-        t = Transition(self._obs_tm1_buf.index_select(0, indices), self._act_tm1_buf.index_select(0, indices),
-                       rew[:, None], self._obs_t_buf.index_select(0, j), self._lms_t_buf.index_select(0, j),
+        t = Transition(self._obs_out(self._obs_tm1_buf.index_select(0, indices)), self._act_tm1_buf.index_select(0, indices),
+                       rew[:, None], self._obs_out(self._obs_t_buf.index_select(0, j)), self._lms_t_buf.index_select(0, j),
                        self._terminal_t_buf.index_select(0, j))
         return t, disc
 

@@ -146,7 +146,8 @@ class FusedLearner:
         if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
             raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         s = K.current_stream()
-        K.check(L.hb_replay_gather(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
+        gather = L.hb_replay_gather_packed if buf.packed else L.hb_replay_gather   # bit-packed rings expand to the same operand
+        K.check(gather(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
                                    K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), K.dptr(indices), B, self.L,
                                    K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew),
                                    K.dptr(self.term), K.dptr(self.disc), int(a.params.n_step), float(a.params.discount),

@@ -36,6 +36,9 @@ class RlaxRainbowParams(NamedTuple):
     distributional: bool = True              # False: scalar double-DQN head (rlax_dqn.py:170-205 spec, BASELINE config 2)
     n_step: int = 1                          # >1: n-step returns assembled at sample time (rainbow/replay_memory.py:316-345 spec);
                                              #     needs inserts of a constant row count (the lock-step self-play driver)
+    packed_obs: bool = False                 # True: last_obs and the observation rings hold bit-packed rows (bitpack.py; 84 B instead of
+                                             #     658 B per observation) and the actor / learner kernels unpack while staging;
+                                             #     inputs and outputs of the agent API accept / return either form
     global_is_max: bool = False              # data-parallel only: normalise the IS weights by the max over ALL ranks' batches (one
                                              #     extra 4-byte all-reduce(max) per update), i.e. exactly the reference's w /= max(w)
                                              #     over the global batch (rlax_rainbow.py:188-189); False: per-rank max

@@ -19,8 +19,8 @@ from .experience_buffer import ExperienceBuffer, _dev
 
 class PriorityBuffer(ExperienceBuffer):
     def __init__(self, observation_len: int, action_len: int, reward_len: int, capacity: int, alpha: float = 0.6,
-                 device=None, seed=0):
-        super().__init__(observation_len, action_len, reward_len, capacity, device=device, seed=seed)
+                 device=None, seed=0, packed=False):
+        super().__init__(observation_len, action_len, reward_len, capacity, device=device, seed=seed, packed=packed)
         from hanabi_hip import SumTree  # HIP-only: raises without a GPU / the compiled library
 
         self.sum_tree = SumTree(capacity, device=self.device)

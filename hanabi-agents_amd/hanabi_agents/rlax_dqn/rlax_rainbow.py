@@ -28,6 +28,7 @@ from typing import Tuple
 import numpy as np
 import torch
 
+from . import bitpack
 from . import learning as L
 from .experience_buffer import ExperienceBuffer
 from .noisy_mlp import NoisyMLP, PlainMLP
@@ -164,11 +165,14 @@ class DQNAgent:
         self._graph1 = self._graph2 = None
         self.train_step = 0
         buf = PriorityBuffer if params.use_priority else ExperienceBuffer
+        # packed_obs: last_obs and the observation rings hold bit-packed rows (bitpack.py); either form is accepted on input
+        self.packed = bool(params.packed_obs)
         self.experience = buf(obs_len, self.n_actions, 1, params.experience_buffer_size, device=self.device,
-                              seed=params.seed)
+                              seed=params.seed, packed=self.packed)
         self.experience.track_wp = params.n_step > 1
-        # the reference keeps last_obs as float64 [N, obs_len] (172 MB at 32k games, C-13); int8 here
-        self.last_obs = torch.zeros((n_games, obs_len), dtype=torch.int8, device=self.device)
+        # the reference keeps last_obs as float64 [N, obs_len] (172 MB at 32k games, C-13); int8 (or packed bits) here
+        self.last_obs = (torch.zeros((n_games, bitpack.words_for(obs_len)), dtype=torch.int32, device=self.device) if self.packed
+                         else torch.zeros((n_games, obs_len), dtype=torch.int8, device=self.device))
         self.requires_vectorized_observation = lambda: True
         self._gen = torch.Generator(device=self.device).manual_seed(params.seed + 1)
         self._last_loss = None
@@ -200,10 +204,9 @@ class DQNAgent:
     # ---- helpers ------------------------------------------------------------------------------------
     def _unpack(self, observations) -> Tuple[torch.Tensor, torch.Tensor, bool]:
         obs, legal = observations[1]
-        on_device = isinstance(obs, torch.Tensor)
-        if on_device:
-            return obs.to(self.device), legal.to(self.device), True
-        return (torch.as_tensor(np.asarray(obs)).to(self.device), torch.as_tensor(np.asarray(legal)).to(self.device), False)
+        on_device = isinstance(obs, torch.Tensor)   # tensors in -> tensor actions out; numpy in -> numpy out (the reference)
+        as_dev = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(self.device)
+        return as_dev(obs), as_dev(legal), on_device
 
     def _vec(self, x, dtype):
         if isinstance(x, torch.Tensor):
@@ -214,7 +217,15 @@ class DQNAgent:
         return torch.rand(n, device=self.device, generator=self._gen)
 
     def _net_input(self, obs):
-        return obs.to(torch.float32)
+        return self._obs_int8(obs).to(torch.float32)
+
+    def _obs_int8(self, obs):
+        """The reference's [N, obs_len] 0/1 layout of an observation batch given in either form."""
+        return bitpack.unpack(obs, self.obs_len) if bitpack.is_packed(obs, self.obs_len) else obs
+
+    def _obs_store(self, obs):
+        """The form last_obs and the rings keep: packed int32 rows (params.packed_obs) or int8."""
+        return self.experience.obs_rows(obs)
 
     def _effective_weights(self):
         """[(W [in,out], bias [out])] of the online net in the GEMM dtype; recomputed only after the weights
@@ -236,12 +247,14 @@ class DQNAgent:
             self._eff_cache = None
         eff = self._effective_weights()
         fl = self._fl
-        if fl is not None and fl.actor is not None and obs.dtype == torch.int8 and self.use_mfma_actor:
-            # hand-written MFMA path: int8 observations in, actions out; no bf16 copy of the observations and no logits in HBM
+        if fl is not None and fl.actor is not None and obs.dtype in (torch.int8, torch.int32) and self.use_mfma_actor:
+            # hand-written MFMA path: int8 or bit-packed observations in, actions out; no bf16 copy of the observations and no
+            # logits in HBM
             fl.pack_actor()
             self._draws += 1
             return fl.actor.act(obs.contiguous(), legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
                                 self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
+        obs = self._obs_int8(obs)
         cd = eff[0][0].dtype
         kp = eff[0][0].shape[0]                     # first-layer K, possibly padded (FusedLearner keeps padded operands)
         if obs.dtype == torch.int8 and cd != torch.float32:
@@ -288,14 +301,14 @@ class DQNAgent:
     def add_experience_first(self, observations, step_types):
         obs, _, _ = self._unpack(observations)
         first = self._vec(step_types, torch.int64) == 0
-        self.last_obs = torch.where(first[:, None], obs.to(torch.int8), self.last_obs)
+        self.last_obs = torch.where(first[:, None], self._obs_store(obs), self.last_obs)
 
     def add_experience(self, observations, actions, rewards, step_types):
         obs, legal, _ = self._unpack(observations)
         st = self._vec(step_types, torch.int64)
         not_first = st != 0
         idx = torch.nonzero(not_first, as_tuple=False)[:, 0]  # keeps row order, like boolean-mask indexing
-        obs8 = obs.to(torch.int8)
+        obs8 = self._obs_store(obs)
         if idx.numel():
             self.experience.add_transitions(
                 self.last_obs.index_select(0, idx),
@@ -317,12 +330,12 @@ class DQNAgent:
             start = buf.oldest_entry
             if self.params.use_priority:  # new leaves enter at max priority (priority_buffer.py:29-32)
                 buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
-            ops.replay_insert(self.last_obs, obs.to(torch.int8).contiguous(), legal.to(torch.int8).contiguous(),
+            ops.replay_insert(self.last_obs, self._obs_store(obs).contiguous(), legal.to(torch.int8).contiguous(),
                               self._vec(actions, torch.int32).contiguous(), self._vec(rewards, torch.float32).contiguous(),
                               self._vec(step_types, torch.int8).contiguous(), buf, start)
             buf._advance(n)
             return
-        obs8 = obs.to(torch.int8)
+        obs8 = self._obs_store(obs)
         st = self._vec(step_types, torch.int64)
         self.experience.add_transitions(self.last_obs, self._vec(actions, torch.int64).reshape(-1, 1),
                                         self._vec(rewards, torch.float32).reshape(-1, 1), obs8, legal,

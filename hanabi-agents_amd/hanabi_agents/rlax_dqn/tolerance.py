@@ -16,27 +16,31 @@ All "rel_l2" figures are ||x_lp - x_fp32||_2 / ||x_fp32||_2 over the whole tenso
 TOLERANCE = {
     "bfloat16": {
         # learner, one update on the same batch / weights / sampling probabilities (FusedLearner vs DQNLearning.loss fp32)
-        "td_abs": 0.03,            # |td_lp - td_fp32| <= td_abs + td_rel * |td_fp32| per sample (td = C51 cross-entropy, ~3.9)
-        "td_rel": 0.01,
-        "loss_rel": 5e-3,          # mean(td * w_IS)
-        "is_weight_abs": 1e-6,     # IS weights never see the GEMM dtype
-        "grad_rel_l2": 0.03,       # dW1, db1, dW2, db2 (merged tensors), each
-        "weights_after_5_steps_rel_l2_of_delta": 0.25,   # ||dw_lp - dw_fp32|| / ||dw_fp32||, dw = w_after - w_before (Adam's
-                                                         # normalised step amplifies sign flips of near-zero gradients)
+        "td_abs": 0.01,            # |td_lp - td_fp32| <= td_abs + td_rel * |td_fp32| per sample (td = C51 cross-entropy, ~4.4) on
+        "td_rel": 0.004,           # every sample whose double-Q selection is unambiguous in fp32 (top-2 q gap > argmax_gap);
+                                   # a near-tie may select the other action, which swaps that sample's whole target
+                                   # (measured worst: 0.0093 on clear samples, 0.32 on a flipped one)
+        "loss_rel": 2e-3,          # mean(td * w_IS)                                              (measured 2.8e-4)
+        "is_weight_abs": 1e-6,     # IS weights never see the GEMM dtype                          (measured 0)
+        "grad_rel_l2": 0.05,       # dW1, db1, dW2, db2 (merged tensors), each, flipped samples included (measured <= 0.030)
+        "weights_after_5_steps_rel_l2_of_delta": 0.12,   # ||dw_lp - dw_fp32|| / ||dw_fp32||, dw = w_after - w_before (Adam's
+                                                         # normalised step amplifies sign flips of near-zero gradients; 0.063)
         "weights_after_5_steps_max_abs": 0.0101,         # <= 2 * lr * steps: no element can be further apart than that
-        # actor: q = mean_k softmax(logits) * atoms (|q| <= 0.49), MFMA kernels vs DQNPolicy.q_values fp32
-        "q_abs": 2e-3,
-        "argmax_gap": 4e-3,        # wherever the fp32 top-2 gap over legal moves exceeds this, the chosen move is the fp32 arg-max
+        # actor: q = mean_k softmax(logits) * atoms (|q| <= 0.49), MFMA kernels vs DQNPolicy.q_values fp32, output layer scaled x4
+        # so that the logits are as large as a trained net's (bf16 rounds logits of magnitude 2-4 to 1/64)
+        "q_abs": 0.03,             # (measured max 0.017, mean 0.0011)
+        "argmax_gap": 0.06,        # wherever the fp32 top-2 gap over legal moves exceeds this, the chosen move is the fp32 arg-max
     },
-    "float16": {
-        "td_abs": 0.005,
-        "td_rel": 0.002,
-        "loss_rel": 1e-3,
+    "float16": {                   # the reference's own network dtype (rlax_rainbow.py:250-251)
+        "td_abs": 0.002,           # (measured worst 0.0011)
+        "td_rel": 0.0005,
+        "loss_rel": 1e-4,          # (measured 1.8e-6)
         "is_weight_abs": 1e-6,
-        "grad_rel_l2": 0.005,
-        "weights_after_5_steps_rel_l2_of_delta": 0.08,
+        "grad_rel_l2": 0.03,       # (measured: output layer 4e-4, hidden layer 0.020 — dLoss/dlogits ~ 1e-5 is subnormal in
+                                   # fp16 and no loss scaling is applied, so dH loses bits; bf16 has the range, not the bits)
+        "weights_after_5_steps_rel_l2_of_delta": 0.12,
         "weights_after_5_steps_max_abs": 0.0101,
-        "q_abs": 3e-4,
-        "argmax_gap": 6e-4,
+        "q_abs": 0.004,            # (measured 0.0020)
+        "argmax_gap": 0.008,
     },
 }

@@ -80,6 +80,7 @@ SIGNATURES = {
     "hb_obs_len": (C.c_int, [_CFG]),
     "hb_deck_size": (C.c_int, [_CFG]),
     "hb_state_words": (C.c_int, [_CFG]),
+    "hb_obs_words": (C.c_int, [_CFG]),
     "hb_env_create": (C.c_int, [_CFG, _I64, _U64, _I64, C.POINTER(_P)]),
     "hb_env_destroy": (C.c_int, [_P]),
     "hb_env_num_games": (_I64, [_P]),
@@ -87,6 +88,10 @@ SIGNATURES = {
     "hb_env_reset": (C.c_int, [_P, _P, _I32, _P]),
     "hb_env_observe": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "hb_env_step": (C.c_int, [_P] + [_P] * 8 + [_P]),
+    "hb_env_observe_packed": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "hb_env_step_packed": (C.c_int, [_P] + [_P] * 9 + [_P]),
+    "hb_obs_pack": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "hb_obs_unpack": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "hb_env_illegal_count": (C.c_int, [_P, C.POINTER(_I64)]),
     "hb_env_stats": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "hb_env_export_state": (C.c_int, [_P, _P, _P]),
@@ -115,12 +120,14 @@ SIGNATURES = {
     "hb_obs_cast": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "hb_policy_act": (C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _I32, C.c_float, _U64, _U64, _I64, _P, _P, _P]),
     "hb_replay_gather": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
+    "hb_replay_gather_packed": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
     "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "hb_noisy_adam": (C.c_int, [_P] * 11 + [_P, _P, _I32, _I64, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_noisy_adam_multi": (C.c_int, [C.POINTER(HbAdamTensor), _I32, _P, C.c_float, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_actor_pack_weights": (C.c_int, [C.POINTER(HbPackJob), _I32, _P]),
     "hb_actor_hidden": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
+    "hb_actor_hidden_packed": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
     "hb_actor_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P]),
     "hb_policy_select": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _U64, _U64, _I64, _P, _P]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),

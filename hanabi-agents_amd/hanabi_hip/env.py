@@ -6,6 +6,12 @@ batched `(observation [N, obs_len], legal_moves [N, n_actions])` int8 tensors, w
 what `DQNAgent.explore/add_experience` consume as `observations[1]`
 (hanabi_agents/rlax_dqn/rlax_rainbow.py:284-308). All buffers are torch CUDA tensors owned by
 this object and rewritten in place by every step (zero host traffic).
+
+`packed=True`: the encoder's native output — `obs_bits [N, obs_words] int32`, observation element i
+= bit i & 31 of word i >> 5 — is what every step writes (84 instead of 658 bytes per game for
+2-player full Hanabi); `obs` is then expanded from it on access (`hb_obs_unpack`), bit for bit what
+the unpacked mode writes. The DQN agent, the replay ring and the actor / learner kernels consume
+the packed rows directly (`RlaxRainbowParams(packed_obs=True)`).
 """
 import ctypes as C
 
@@ -17,7 +23,7 @@ from . import _capi as K
 class HanabiEnv:
     def __init__(self, game="Hanabi-Full", players=2, n_games=1, seed=1234, first_game_id=0, auto_reset=True,
                  lockstep=True, lenient_reward=False, device=None, config=None, decks=None, start_player=0,
-                 games_per_wave=None):
+                 games_per_wave=None, packed=False):
         if not torch.cuda.is_available():
             raise K.HbError("HanabiEnv needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
         self.L = K.lib()
@@ -31,6 +37,8 @@ class HanabiEnv:
         self.obs_len = self.L.hb_obs_len(C.byref(self.cfg))
         self.deck_size = self.L.hb_deck_size(C.byref(self.cfg))
         self.state_words = self.L.hb_state_words(C.byref(self.cfg))
+        self.obs_words = self.L.hb_obs_words(C.byref(self.cfg))
+        self.packed = bool(packed)
         self.first_game_id = int(first_game_id)
         self.seed = int(seed)
         h = C.c_void_p()
@@ -38,7 +46,9 @@ class HanabiEnv:
             K.check(self.L.hb_env_create(C.byref(self.cfg), self.n, seed, first_game_id, C.byref(h)))
         self.h = h
         dev = self.device
-        self.obs = torch.zeros((self.n, self.obs_len), dtype=torch.int8, device=dev)
+        self._obs = torch.zeros((self.n, self.obs_len), dtype=torch.int8, device=dev)
+        self.obs_bits = torch.zeros((self.n, self.obs_words), dtype=torch.int32, device=dev) if self.packed else None
+        self._obs_stale = False    # packed mode: `_obs` lags `obs_bits` until someone asks for it
         self.legal = torch.zeros((self.n, self.num_actions), dtype=torch.int8, device=dev)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.terminal = torch.zeros(self.n, dtype=torch.int8, device=dev)
@@ -51,6 +61,19 @@ class HanabiEnv:
         if decks is not None:
             self.set_decks(decks)
         self.reset(start_player=start_player)
+
+    @property
+    def obs(self):
+        """[N, obs_len] int8 0/1, the reference's layout. Packed mode: expanded from `obs_bits` when first read after a step."""
+        if self._obs_stale:
+            K.check(self.L.hb_obs_unpack(K.dptr(self.obs_bits), K.dptr(self._obs), self.n, self.obs_len, K.current_stream()))
+            self._obs_stale = False
+        return self._obs
+
+    @property
+    def net_obs(self):
+        """What the agents are fed: the packed rows in packed mode, else `obs`."""
+        return self.obs_bits if self.packed else self._obs
 
     def __del__(self):
         h = getattr(self, "h", None)
@@ -93,9 +116,14 @@ class HanabiEnv:
         return self.observe()
 
     def observe(self):
-        K.check(self.L.hb_env_observe(self.h, K.dptr(self.obs), K.dptr(self.legal), K.dptr(self.agent_reward),
+        if self.packed:
+            K.check(self.L.hb_env_observe_packed(self.h, K.dptr(self.obs_bits), None, K.dptr(self.legal), K.dptr(self.agent_reward),
+                                                 K.dptr(self.agent_step_type), K.current_stream()))
+            self._obs_stale = True
+            return self.obs_bits, self.legal
+        K.check(self.L.hb_env_observe(self.h, K.dptr(self._obs), K.dptr(self.legal), K.dptr(self.agent_reward),
                                       K.dptr(self.agent_step_type), K.current_stream()))
-        return self.obs, self.legal
+        return self._obs, self.legal
 
     def step(self, actions):
         """actions: int32 CUDA tensor [N] of move uids. Returns (obs, legal, reward, terminal) views."""
@@ -103,10 +131,16 @@ class HanabiEnv:
         if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()):
             a = torch.as_tensor(a).to(device=self.device, dtype=torch.int32).contiguous()
         assert a.shape == (self.n,)
-        K.check(self.L.hb_env_step(self.h, K.dptr(a), K.dptr(self.obs), K.dptr(self.legal), K.dptr(self.reward),
+        if self.packed:
+            K.check(self.L.hb_env_step_packed(self.h, K.dptr(a), K.dptr(self.obs_bits), None, K.dptr(self.legal), K.dptr(self.reward),
+                                              K.dptr(self.terminal), K.dptr(self.agent_reward), K.dptr(self.agent_step_type),
+                                              K.dptr(self.score), K.current_stream()))
+            self._obs_stale = True
+            return self.obs_bits, self.legal, self.reward, self.terminal
+        K.check(self.L.hb_env_step(self.h, K.dptr(a), K.dptr(self._obs), K.dptr(self.legal), K.dptr(self.reward),
                                    K.dptr(self.terminal), K.dptr(self.agent_reward), K.dptr(self.agent_step_type),
                                    K.dptr(self.score), K.current_stream()))
-        return self.obs, self.legal, self.reward, self.terminal
+        return self._obs, self.legal, self.reward, self.terminal
 
     def random_legal_actions(self, seed, draw, out=None):
         """Uniform-random legal move per game (bench / tests policy)."""

@@ -33,8 +33,10 @@ def obs_cast(obs, dtype, out=None):
 
 def replay_insert(last_obs, obs, legal, actions, rewards, step_types, ring, start):
     """ring: object with _obs_tm1_buf, _obs_t_buf, _act_tm1_buf, _lms_t_buf, _rew_t_buf, _terminal_t_buf, capacity."""
-    n, obs_len = obs.shape
-    for t, dt in ((last_obs, torch.int8), (obs, torch.int8), (legal, torch.int8), (actions, torch.int32),
+    odt = ring._obs_tm1_buf.dtype          # int8 rows of obs_len bytes, or bit-packed int32 rows: plain bytes to the kernel
+    n, obs_len = obs.shape[0], obs.shape[1] * obs.element_size()
+    assert last_obs.shape == obs.shape and ring._obs_tm1_buf.shape[1] == obs.shape[1]
+    for t, dt in ((last_obs, odt), (obs, odt), (legal, torch.int8), (actions, torch.int32),
                   (rewards, torch.float32), (step_types, torch.int8)):
         assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (t.dtype, dt)
     K.check(K.lib().hb_replay_insert(K.dptr(last_obs), K.dptr(obs), K.dptr(legal), K.dptr(actions), K.dptr(rewards),
@@ -77,15 +79,17 @@ class ActorMFMA:
 
     def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0):
         n = obs.shape[0]
-        assert obs.dtype == torch.int8 and obs.is_contiguous() and obs.shape[1] == self.obs_len
+        packed = obs.dtype == torch.int32
+        assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
+                                        (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
         assert legal.dtype == torch.int8 and legal.is_contiguous() and legal.shape == (n, self.n_actions)
         if self.h is None or self.h.shape[0] != n:
             self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
         actions = torch.empty(n, dtype=torch.int32, device=obs.device)
         L, s = K.lib(), K.current_stream()
-        K.check(L.hb_actor_hidden(K.dptr(obs), n, self.obs_len, K.dptr(self.w1t), self.k_pad, K.dptr(self.b1), self.hidden,
-                                  K.dptr(self.h), s))
+        hidden = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden   # bit rows are unpacked while staged into LDS
+        K.check(hidden(K.dptr(obs), n, self.obs_len, K.dptr(self.w1t), self.k_pad, K.dptr(self.b1), self.hidden, K.dptr(self.h), s))
         K.check(L.hb_actor_q(K.dptr(self.h), n, self.hidden, K.dptr(self.w2t), K.dptr(self.b2), K.dptr(support), self.n_actions,
                              self.n_atoms, K.dptr(self.q), s))
         K.check(L.hb_policy_select(K.dptr(self.q), K.dptr(legal), n, self.n_actions, float(epsilon), int(seed), int(draw),

@@ -72,7 +72,7 @@ class SelfPlaySession:
             main.wait_event(self._update_done.pop(id(agent)))  # its replay / weights are being written by that update
         # [0]: the rich observation source for agents with requires_vectorized_observation() False (rule-based
         # partners read the env's state rows); [1]: the vectorised (obs, legal) pair the DQN agents use
-        observations = (env, (env.obs, env.legal))
+        observations = (env, (env.net_obs, env.legal))   # packed env: the bit rows, which the agents take as they are
         if self.t < env.players:
             # only during the first round can a seat be without a pending move (step type FIRST)
             agent.add_experience_first(observations, env.agent_step_type)

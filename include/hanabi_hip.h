@@ -77,6 +77,7 @@ int hb_num_actions(const hb_config* cfg);   /* 2*hand + (P-1)*(colors+ranks): 20
 int hb_obs_len(const hb_config* cfg);       /* canonical encoding length: 658 / 1280 / 171 */
 int hb_deck_size(const hb_config* cfg);     /* 50 / 20 */
 int hb_state_words(const hb_config* cfg);   /* u32 words per game-state row: 32 (P<=3) or 48 */
+int hb_obs_words(const hb_config* cfg);     /* u32 words of a bit-packed observation row: ceil(obs_len / 32) = 21 / 40 / 6 */
 
 /* ---- vectorised environment ----------------------------------------------------------
  * N independent games. Game state lives in HBM as one row of hb_state_words() u32 per
@@ -128,6 +129,23 @@ int hb_env_observe(hb_env* env, int8_t* obs_dev, int8_t* legal_dev, float* agent
 int hb_env_step(hb_env* env, const int32_t* actions_dev, int8_t* obs_dev, int8_t* legal_dev,
                 float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev,
                 int8_t* agent_step_type_dev, int8_t* score_dev, void* stream);
+
+/* Bit-packed form of the same observation. The encoder builds every observation as hb_obs_words() u32 of bits before it
+ * expands them to the reference's int8 layout; these entry points hand that form out directly:
+ *   obs_bits_dev [n, hb_obs_words()] u32 (16-byte aligned; required): observation element i of game g is
+ *                bit (i & 31) of word i >> 5 of row g; the pad bits of the last word are zero;
+ *   obs_dev      the int8 [n, obs_len] form as well, or NULL to skip it (658 -> 84 bytes written per game for
+ *                2-player full Hanabi). hb_obs_unpack of obs_bits_dev gives exactly what obs_dev would have held.
+ * Everything else is as in hb_env_observe / hb_env_step. Consumers: hb_replay_insert (rows are plain bytes: pass
+ * obs_len = 4 * hb_obs_words()), hb_replay_gather_packed, hb_actor_hidden_packed.                                   */
+int hb_env_observe_packed(hb_env* env, uint32_t* obs_bits_dev, int8_t* obs_dev, int8_t* legal_dev, float* agent_reward_dev,
+                          int8_t* agent_step_type_dev, void* stream);
+int hb_env_step_packed(hb_env* env, const int32_t* actions_dev, uint32_t* obs_bits_dev, int8_t* obs_dev, int8_t* legal_dev,
+                       float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev,
+                       int8_t* score_dev, void* stream);
+/* int8 0/1 rows [rows, obs_len] <-> packed rows [rows, ceil(obs_len / 32)] u32 (any nonzero byte packs to 1).        */
+int hb_obs_pack(const int8_t* obs_dev, uint32_t* bits_dev, int64_t rows, int32_t obs_len, void* stream);
+int hb_obs_unpack(const uint32_t* bits_dev, int8_t* obs_dev, int64_t rows, int32_t obs_len, void* stream);
 
 /* Number of illegal uids seen since creation (synchronises the stream).                */
 int hb_env_illegal_count(hb_env* env, int64_t* out);
@@ -313,6 +331,14 @@ int hb_replay_gather(const int8_t* ring_obs_tm1_dev, const int8_t* ring_obs_t_de
                      float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert,
                      const int64_t* size_wp_dev, void* stream);
 
+/* The same gather from bit-packed rings (rows of ceil(obs_len / 32) u32, see hb_env_step_packed): x_dev receives the
+ * identical 0 / 1 operand.                                                                                              */
+int hb_replay_gather_packed(const uint32_t* ring_bits_tm1_dev, const uint32_t* ring_bits_t_dev, const int8_t* ring_act_dev,
+                            const float* ring_rew_dev, const uint8_t* ring_term_dev, const int64_t* idx_dev, int64_t batch,
+                            int32_t obs_len, void* x_dev, int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev,
+                            float* term_dev, float* disc_dev, int32_t n_step, float gamma, int64_t capacity,
+                            int64_t rows_per_insert, const int64_t* size_wp_dev, void* stream);
+
 /* hb_c51_loss_grad: rlax_rainbow.py:172-200 on precomputed logits.
  *   logits_online_dev [2B, row_stride >= A*K]: rows 0..B-1 = online(obs_tm1), rows B..2B-1 = online(obs_t);
  *   logits_target_dev [B, A*K] = target(obs_t); support_dev [K] uniform atoms.
@@ -394,6 +420,9 @@ int hb_actor_pack_weights(const hb_pack_job* jobs /* host array of device pointe
                           void* stream);
 int hb_actor_hidden(const int8_t* obs_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev, int32_t k_pad,
                     const float* b1_dev, int32_t hidden, void* h_dev, void* stream);
+/* hb_actor_hidden on bit-packed observation rows [n_rows, ceil(obs_len / 32)] u32 (hb_env_step_packed): bit-identical h_dev */
+int hb_actor_hidden_packed(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev, int32_t k_pad,
+                           const float* b1_dev, int32_t hidden, void* h_dev, void* stream);
 int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev,
                const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, void* stream);
 int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_games, int32_t n_actions, float epsilon,

@@ -9,12 +9,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _pair(game, players, n, seed=7, flags=O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT, decks=None, gpw=None,
-          first_game_id=0):
+          first_game_id=0, packed=False):
     import hanabi_hip
 
     cfg = hanabi_hip.make_config(game, players, flags)
     env = hanabi_hip.HanabiEnv(config=cfg, n_games=n, seed=seed, first_game_id=first_game_id, decks=decks,
-                               games_per_wave=gpw)
+                               games_per_wave=gpw, packed=packed)
     orc = O.OracleEnv(O.make_config(game, players, flags), n, seed=seed, first_game_id=first_game_id, decks=decks)
     return env, orc
 
@@ -23,6 +23,14 @@ def _assert_same(env, orc, out, what):
     import torch
 
     torch.cuda.synchronize()
+    if env.packed:
+        # the kernel wrote ONLY the bit rows (hb_env_step_packed): they must be the oracle's observation packed 32 per word,
+        # pad bits zero; env.obs below is then hb_obs_unpack of them
+        want = np.zeros((env.n, env.obs_words * 32), np.uint8)
+        want[:, :env.obs_len] = out["obs"]
+        want = np.packbits(want, axis=1, bitorder="little").view(np.uint32)
+        got = env.obs_bits.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), f"{what}: packed observation differs in {np.argwhere(got != want)[:5]}"
     for name, t in (("obs", env.obs), ("legal", env.legal), ("agent_reward", env.agent_reward),
                     ("agent_step_type", env.agent_step_type)):
         got = t.cpu().numpy()
@@ -40,10 +48,11 @@ def _assert_same(env, orc, out, what):
     ("Hanabi-Small", 2, 500, 64), ("Hanabi-Small", 5, 130, 32), ("Hanabi-Very-Small", 2, 64, 64),
     ("Hanabi-Very-Small", 5, 65, 16), ("Hanabi-Full", 2, 1, 64), ("Hanabi-Small", 3, 17, 64),
 ])
-def test_random_self_play_bit_exact(game, players, n, gpw):
-    """Random-legal self-play with auto-reset: obs, legal, rewards, step types and the raw state
-    rows stay identical to the oracle for hundreds of moves (several episodes per game)."""
-    env, orc = _pair(game, players, n, gpw=gpw, first_game_id=12345)
+@pytest.mark.parametrize("packed", [False, True])
+def test_random_self_play_bit_exact(game, players, n, gpw, packed):
+    """Random-legal self-play with auto-reset: obs (int8 form, and the bit-packed form when the env emits that), legal,
+    rewards, step types and the raw state rows stay identical to the oracle for hundreds of moves (several episodes per game)."""
+    env, orc = _pair(game, players, n, gpw=gpw, first_game_id=12345, packed=packed)
     _assert_same(env, orc, orc.observe(), "after reset")
     steps = 150 if game == "Hanabi-Full" else 80
     for t in range(steps):
@@ -198,7 +207,8 @@ def test_arbitrary_uids_all_variants(game, players):
     import torch
 
     for extra in (0, O.FLAG_LENIENT_REWARD):
-        env, orc = _pair(game, players, 96, seed=31 + players, flags=O.FLAG_AUTO_RESET | extra, first_game_id=7)
+        env, orc = _pair(game, players, 96, seed=31 + players, flags=O.FLAG_AUTO_RESET | extra, first_game_id=7,
+                         packed=bool(extra))
         rng = np.random.default_rng(players * 10 + len(game))
         for t in range(70):
             act = rng.integers(-2, env.num_actions + 2, 96).astype(np.int32)
