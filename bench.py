@@ -64,6 +64,8 @@ def parse():
                     help="reserve this many CUs for the learner stream (CU-masked streams); 0 = no partition")
     ap.add_argument("--no-learner-stream", action="store_true", help="run the updates in order on the main stream")
     ap.add_argument("--learner-priority", type=int, default=-1, help="HIP stream priority of the learner stream (-1 = high)")
+    ap.add_argument("--unpacked-obs", action="store_true",
+                    help="int8 [N, obs_len] observations end to end (the reference's layout) instead of the bit-packed rows")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous the ranks and all-reduce one number (works without a GPU: gloo); tests the launcher")
     return ap.parse_args()
@@ -285,14 +287,18 @@ def main():
     n = args.games
     flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
     env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", args.players, flags), n_games=n, seed=1234,
-                               first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device)
-    bytes_per_step = env.obs_len + env.num_actions + 9 + 2 * env.state_words * 4
+                               first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device,
+                               packed=not args.unpacked_obs)
+    # obs + legal + action/reward/step-type (9) + state row read and written. In packed mode the observation
+    # leaves the kernel as obs_words u32 instead of obs_len bytes (84 vs 658 for 2 players); both figures are reported.
+    bytes_int8_form = env.obs_len + env.num_actions + 9 + 2 * env.state_words * 4
+    bytes_per_step = (env.obs_words * 4 if env.packed else env.obs_len) + env.num_actions + 9 + 2 * env.state_words * 4
 
     agents = []
     session = None
     main_stream = None
     if not args.env_only:
-        params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank)
+        params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=env.packed)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
                            params._replace(seed=1234 + 17 * s), device=device) for s in range(args.players)]
         for a in agents:
@@ -387,16 +393,20 @@ def main():
         "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
         "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n,
+                     "traffic": None, "bytes_per_env_step": bytes_per_step, "bytes_per_env_step_int8_form": bytes_int8_form,
+                     "observation_form": "bit-packed u32 rows (hb_env_step_packed)" if env.packed else "int8 [N, obs_len] (hb_env_step)",
+                     "env_steps_per_launch": n,
                      "avg_launch_us": kernel_avg_s * 1e6, "median_launch_us": kernel_ms[len(kernel_ms) // 2] * 1e3,
                      "kernel_only_env_steps_per_sec": n / kernel_avg_s},
     }
     # HBM traffic of the same kernel/config from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE; profiles/): PMC counters cannot be read from inside this process
-    pmc = os.path.join(ROOT, "profiles", "r01", "env_kernel_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r02", "env_kernel_pmc_traffic_packed.json" if env.packed else "env_kernel_pmc_traffic.json")
+    if not env.packed and not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01", "env_kernel_pmc_traffic.json")
     if n == 32768 and args.players == 2 and os.path.exists(pmc):
         line["roofline"]["traffic"] = json.load(open(pmc))["per_launch_bytes"]["total"]
-        line["roofline"]["traffic_source"] = "profiles/r01/env_kernel_pmc_traffic.json (rocprofv3 --pmc, separate passes)"
+        line["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc, separate passes)"
     if session is not None:
         line["mean_episode_score"] = session.mean_score()
         # the same kernel with the GPU to itself (random-legal policy, no agents): inside the loop it shares the chip with
@@ -417,6 +427,23 @@ def main():
         line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_per_step / alone_s / 1e9,
                                           "frac": n * bytes_per_step / alone_s / 1e9 / HBM_PEAK_GBS,
                                           "note": "same kernel, env-only stepping after the timed region (50 launches)"}
+        if env.packed:
+            # the reference-shaped output of the same kernel (int8 [N, obs_len], SURVEY §8(d)'s 943 B per env-step), env-only
+            env8 = hanabi_hip.HanabiEnv(config=env.cfg, n_games=n, seed=1234, first_game_id=rank * n,
+                                        games_per_wave=args.games_per_wave, device=device, packed=False)
+            for k in range(60):
+                env8.set_profile_events(*sa[k])
+                env8.random_legal_actions(4321, 20_000 + k, out=act)
+                env8.step(act)
+            torch.cuda.synchronize()
+            env8.set_profile_events(None, None)
+            t8 = sorted(a.elapsed_time(b) for a, b in sa[10:])
+            t8_s = sum(t8) / len(t8) / 1e3
+            line["roofline"]["int8_form"] = {"bytes_per_env_step": bytes_int8_form, "avg_launch_us": t8_s * 1e6,
+                                             "achieved": n * bytes_int8_form / t8_s / 1e9,
+                                             "frac": n * bytes_int8_form / t8_s / 1e9 / HBM_PEAK_GBS,
+                                             "note": "hb_env_step writing int8 [N, obs_len] observations, env-only (50 launches)"}
+            del env8
         # every rank runs it (the learner update inside contains the gradient all-reduce); rank 0's numbers are printed
         line["roofline_qnet"] = qnet_roofline(agents[0], env, args)
         if rank == 0:
@@ -444,7 +471,7 @@ def qnet_roofline(agent, env, args):
     n = env.n
     hidden = agent.params.layers[0]
     fwd_flop = 4.0 * (env.obs_len * hidden + hidden * env.num_actions * agent.params.n_atoms)  # per sample
-    obs = (None, (env.obs, env.legal))
+    obs = (None, (env.net_obs, env.legal))
     for _ in range(3):
         agent.explore(obs)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -470,11 +497,12 @@ def qnet_roofline(agent, env, args):
         from hanabi_hip import _capi as K
 
         ac, L, s = fl0.actor, K.lib(), K.current_stream()
-        obs8, legal8, support = env.obs, env.legal, agent.atoms[0].contiguous()
-        acts = torch.empty(n, dtype=torch.int32, device=env.obs.device)
+        obs8, legal8, support = env.net_obs, env.legal, agent.atoms[0].contiguous()
+        acts = torch.empty(n, dtype=torch.int32, device=legal8.device)
+        hidden_fn = L.hb_actor_hidden_packed if env.packed else L.hb_actor_hidden
         launches = {
-            "hb_actor_hidden": lambda: L.hb_actor_hidden(K.dptr(obs8), n, ac.obs_len, K.dptr(ac.w1t), ac.k_pad, K.dptr(ac.b1), ac.hidden,
-                                                         K.dptr(ac.h), s),
+            "hb_actor_hidden": lambda: hidden_fn(K.dptr(obs8), n, ac.obs_len, K.dptr(ac.w1t), ac.k_pad, K.dptr(ac.b1), ac.hidden,
+                                                 K.dptr(ac.h), s),
             "hb_actor_q": lambda: L.hb_actor_q(K.dptr(ac.h), n, ac.hidden, K.dptr(ac.w2t), K.dptr(ac.b2), K.dptr(support), ac.n_actions,
                                                ac.n_atoms, K.dptr(ac.q), s),
             "hb_policy_select": lambda: L.hb_policy_select(K.dptr(ac.q), K.dptr(legal8), n, ac.n_actions, 0.1, 1, 1, 0, K.dptr(acts), s),

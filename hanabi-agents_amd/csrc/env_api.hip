@@ -135,7 +135,7 @@ int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t 
   HB_HIP_OR(hipGetDevice(&e->device), delete e);
   const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
-  e->stat_slots = n_games / 16 + 8;  // one slot per wavefront at the smallest games-per-wave setting
+  e->stat_slots = n_games / 8 + 8;  // one slot per wavefront at the smallest games-per-wave setting
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->illegal), 8 + 16 * e->stat_slots), { (void)hipFree(e->state); delete e; });
   HB_HIP_OR(hipMemset(e->state, 0, bytes), { hb_env_destroy(e); });
   HB_HIP_OR(hipMemset(e->illegal, 0, 8 + 16 * e->stat_slots), { hb_env_destroy(e); });
@@ -176,7 +176,7 @@ int hb_env_set_decks(hb_env* e, const uint8_t* decks_dev) {
 
 int hb_env_set_games_per_wave(hb_env* e, int32_t g) {
   if (!e) return fail(HB_ERR_INVALID, "null env");
-  if (g != 16 && g != 32 && g != 64) return fail(HB_ERR_INVALID, "games per wave must be 16, 32 or 64");
+  if (g != 8 && g != 16 && g != 32 && g != 64) return fail(HB_ERR_INVALID, "games per wave must be 8, 16, 32 or 64");
   e->gpw = g;
   return HB_OK;
 }
@@ -245,7 +245,7 @@ static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.flags = e->cfg.flags;
   a.ev_start = e->ev_start;
   a.ev_stop = e->ev_stop;
-  hb::LaunchFn fn = e->gpw == 16 ? e->var->g16 : (e->gpw == 32 ? e->var->g32 : e->var->g64);
+  hb::LaunchFn fn = e->gpw == 8 ? e->var->g8 : (e->gpw == 16 ? e->var->g16 : (e->gpw == 32 ? e->var->g32 : e->var->g64));
   fn(a, static_cast<hipStream_t>(stream));
   HB_HIP(hipGetLastError());
   return HB_OK;

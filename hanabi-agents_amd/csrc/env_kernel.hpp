@@ -737,13 +737,13 @@ using LaunchFn = void (*)(const EnvArgs&, hipStream_t);
 struct EnvVariant {
   int P, C, R, H, INFO, LIFE;
   int obs_len, n_actions, deck, state_words;
-  LaunchFn g16, g32, g64, refill;
+  LaunchFn g8, g16, g32, g64, refill;
 };
 
 template <class K>
 constexpr EnvVariant make_variant() {
   return EnvVariant{K::P, K::C, K::R, K::H, K::INFO, K::LIFE, K::OBS_LEN, K::A, K::D, K::SW,
-                    &launch_env<K, 16>, &launch_env<K, 32>, &launch_env<K, 64>, &launch_refill<K>};
+                    &launch_env<K, 8>, &launch_env<K, 16>, &launch_env<K, 32>, &launch_env<K, 64>, &launch_refill<K>};
 }
 
 }  // namespace hb

@@ -111,7 +111,7 @@ def test_fused_learner_reduced_precision_vs_fp32_autograd(dtype, players):
     with torch.no_grad():
         q_sel = L.expected_q(ref.online(trf.observation_t).view(n, n_act, 51), ref.atoms)
     top2 = q_sel.topk(2, dim=1).values
-    clear = (top2[:, 0] - top2[:, 1]) > tol["argmax_gap"]
+    clear = (top2[:, 0] - top2[:, 1]) > tol["selection_gap"]
 
     # ---- one update on both ------------------------------------------------------------------------------------------
     fused.update()
