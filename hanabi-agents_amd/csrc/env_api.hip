@@ -73,6 +73,10 @@ struct hb_env {
   hipEvent_t ev_step_done, ev_refill_done;
   bool refill_in_flight;
   bool async_refill;
+  // A game cannot end in fewer than max_life moves (the quickest ending is max_life misplays in a row), so a pool deck
+  // consumed by a re-deal at step t is not needed again before step t + max_life: the refill launch runs every
+  // `refill_period` = min(max_life, 3) steps instead of after every step (Hanabi-Full: 1 launch in 3; -Small: every step)
+  int refill_period, since_refill;
 };
 
 using hb::fail;
@@ -132,6 +136,8 @@ int hb_env_create(const hb_config* cfg, int64_t n_games, uint64_t seed, int64_t 
   e->ev_step_done = e->ev_refill_done = nullptr;
   e->refill_in_flight = false;
   e->async_refill = false;
+  e->refill_period = cfg->max_life < 3 ? cfg->max_life : 3;
+  e->since_refill = 0;
   HB_HIP_OR(hipGetDevice(&e->device), delete e);
   const size_t bytes = static_cast<size_t>(n_games) * var->state_words * 4;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&e->state), bytes), delete e);
@@ -213,6 +219,7 @@ static int join_refill(hb_env* e, void* stream) {
 
 // regenerate consumed / stale deck-pool entries (cheap when nothing is flagged), in order on `stream`
 static int refill(hb_env* e, void* stream) {
+  e->since_refill = 0;
   hb::EnvArgs a{};
   fill_common(e, a);
   e->var->refill(a, static_cast<hipStream_t>(stream));
@@ -223,6 +230,7 @@ static int refill(hb_env* e, void* stream) {
 // same, but forked onto the env's private stream behind everything enqueued on `stream` so far; the next call
 // that needs the pool joins it (join_refill)
 static int refill_async(hb_env* e, void* stream) {
+  if (++e->since_refill < e->refill_period) return HB_OK;  // no game can need a second deck yet
   if (!e->async_refill) return refill(e, stream);
   HB_HIP(hipEventRecord(e->ev_step_done, static_cast<hipStream_t>(stream)));
   HB_HIP(hipStreamWaitEvent(e->side, e->ev_step_done, 0));
@@ -379,6 +387,13 @@ int hb_env_stats(hb_env* e, int64_t* episodes, int64_t* score_sum) {
   for (long long i = 0; i < e->stat_slots; ++i) { ep += v[2 * i]; sc += v[2 * i + 1]; }
   *episodes = static_cast<int64_t>(ep);
   *score_sum = static_cast<int64_t>(sc);
+  return HB_OK;
+}
+
+int hb_env_set_refill_period(hb_env* e, int32_t steps) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (steps < 1 || steps > e->cfg.max_life) return fail(HB_ERR_INVALID, "refill period must be 1..max_life (%d)", e->cfg.max_life);
+  e->refill_period = steps;
   return HB_OK;
 }
 

@@ -1,4 +1,4 @@
-"""FusedLearner — one learner update as ~30 launches instead of ~250 (GPU only).
+"""FusedLearner — one learner update as ~10 launches instead of ~250 (GPU only).
 
 Same arithmetic as `DQNLearning.loss` + `torch.optim.Adam` on the NoisyMLP (the PyTorch-autograd
 path in rlax_rainbow.py stays as the fp32 reference and is what runs on the CPU), arranged as
@@ -7,9 +7,10 @@ path in rlax_rainbow.py stays as the fp32 reference and is what runs on the CPU)
     ->  online and target passes together: one GEMM per layer (layer 1 on the concatenated [W1 | W1_target], layer 2
         as a batched GEMM over the two networks), effective weights W = w + w_mu + w_sigma*eps already materialised in
         the GEMM dtype
-    ->  hb_c51_loss_grad: IS weights, double-Q selection, projection, cross-entropy, dLoss/dlogits
-    ->  backward by hand: dW2 = H^T dlogits, dH = dlogits W2^T masked by ReLU, dW1 = X^T dH,
-        bias grads by column sums
+    ->  hb_c51_loss_sparse: IS weights, double-Q selection, projection, cross-entropy, and dLoss/dlogits in its compact
+        form (non-zero only in the K atoms of the action each sample took: [B, 64] fp32)
+    ->  backward by hand: hb_c51_backward (one launch: dH masked by the ReLU, db1, dW2, db2 from the compact gradient,
+        fixed summation order), then dW1 = X^T dH (GEMM)
     [-> when data-parallel: packed into ONE flat fp32 buffer and all-reduced over RCCL]
     ->  hb_noisy_adam per merged tensor: routes the gradient to (w, w_mu, w_sigma) as (g, g, g*eps), Adam on
         each, and emits the next effective weight
@@ -88,7 +89,10 @@ class FusedLearner:
         self.disc = torch.empty(B, **f32)
         self.td = torch.empty(B, **f32)
         self.w_is = torch.empty(B, **f32)
-        self.dlogits = torch.zeros(B, self.Np, dtype=self.cd, device=dev)
+        self.dlogits = torch.zeros(B, self.Np, dtype=self.cd, device=dev)   # dense dLoss/dlogits (sparse_backward False only)
+        self.dl = torch.zeros(B, 64, **f32)                                # compact dLoss/dlogits: the K atoms of the taken action
+        self.dh = torch.zeros(B, H, dtype=self.cd, device=dev)
+        self.sparse_backward = self.Kk <= 64 and self.A <= 64
         self.AK = AK
         self.support = agent.atoms[0].contiguous()
         self._gb2_pad = torch.zeros(self.Np, **f32)
@@ -157,16 +161,30 @@ class FusedLearner:
         hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
         logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy
         logits_on, logits_t = logits[0], logits[1, B:]                                   # online on all 2B rows, target on obs_t
-        K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
-                                   K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
-                                   1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
-                                   K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step),
-                                   K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
-        hb, xb, dl = hcat[:B, :H], self.x[:B], self.dlogits
-        torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
-        K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
-        dh = torch.mm(dl, w2.t())                                      # masked by the ReLU in place, with its column sums
-        K.check(L.hb_relu_bwd_colsum(K.dptr(dh), K.dptr(hb), hb.stride(0), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
+        hb, xb = hcat[:B, :H], self.x[:B]
+        if self.sparse_backward:
+            # dLoss/dlogits is non-zero only in the K atoms of the action each sample took: the loss kernel emits that compact
+            # [B, 64] fp32 form and ONE launch turns it into dH (ReLU-masked), db1, dW2 and db2 (csrc/learner2.hip)
+            K.check(L.hb_c51_loss_sparse(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
+                                         K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
+                                         1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
+                                         K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dl), K.dptr(self.step),
+                                         K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
+            K.check(L.hb_c51_backward(K.dptr(self.dl), K.dptr(self.act), K.dptr(hb), hb.stride(0), K.dptr(w2), w2.stride(0),
+                                      _DT[self.cd], B, H, self.A, self.Kk, K.dptr(self.dh), K.dptr(self.g_b1),
+                                      K.dptr(self._gw2_out), self.Np, K.dptr(self._gb2_pad), s))
+            dh = self.dh
+        else:   # the dense chain of the first fused learner: kept as a cross-check (tests) of the sparse kernels
+            K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
+                                       K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
+                                       1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
+                                       K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step),
+                                       K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
+            dl = self.dlogits
+            torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
+            K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))
+            dh = torch.mm(dl, w2.t())                                      # masked by the ReLU in place, with its column sums
+            K.check(L.hb_relu_bwd_colsum(K.dptr(dh), K.dptr(hb), hb.stride(0), _DT[self.cd], B, dh.shape[1], K.dptr(self.g_b1), s))
         torch.mm(xb.t(), dh, out=self._gw1_out)                       # [Kp, H]; the padding rows are never read
         if not self.direct:  # pack the all-reduce bucket (fp32, unpadded)
             self.g_w2.copy_(self._gw2_out[:, :self.AK])

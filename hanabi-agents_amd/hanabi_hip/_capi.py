@@ -101,6 +101,7 @@ SIGNATURES = {
     "hb_random_legal_actions": (C.c_int, [_P, _I64, _I32, _U64, _U64, _I64, _P, _P]),
     "hb_env_set_games_per_wave": (C.c_int, [_P, _I32]),
     "hb_env_set_async_refill": (C.c_int, [_P, _I32]),
+    "hb_env_set_refill_period": (C.c_int, [_P, _I32]),
     "hb_env_set_profile_events": (C.c_int, [_P, _P, _P]),
     "hb_tree_create": (C.c_int, [_I64, C.POINTER(_P)]),
     "hb_tree_destroy": (C.c_int, [_P]),
@@ -122,6 +123,8 @@ SIGNATURES = {
     "hb_replay_gather": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
     "hb_replay_gather_packed": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
     "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "hb_c51_loss_sparse": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "hb_c51_backward": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "hb_noisy_adam": (C.c_int, [_P] * 11 + [_P, _P, _I32, _I64, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_noisy_adam_multi": (C.c_int, [C.POINTER(HbAdamTensor), _I32, _P, C.c_float, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),

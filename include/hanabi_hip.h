@@ -218,6 +218,10 @@ int hb_env_set_games_per_wave(hb_env* env, int32_t g);
  * it overlaps the caller's following work — worthwhile only when the caller is not launch-bound (the fork /
  * join costs four extra runtime calls per step; measured slower in bench.py). Synchronises the device.    */
 int hb_env_set_async_refill(hb_env* env, int32_t on);
+/* How often that second kernel runs: every `steps` calls of hb_env_step (1..max_life). A game cannot end in fewer than
+ * max_life moves, so a pooled deck consumed at step t is not needed again before step t + max_life; the default is
+ * min(max_life, 3). Results do not depend on it (deck(g, e) is a pure function of seed, game id and deal counter).       */
+int hb_env_set_refill_period(hb_env* env, int32_t steps);
 
 /* Measurement hook: when both are non-NULL (hipEvent_t handles), every following env kernel
  * launch records its own start/stop into them (hipExtLaunchKernelGGL), i.e. the dispatch's
@@ -355,6 +359,32 @@ int hb_c51_loss_grad(const void* logits_online_dev, const void* logits_target_de
                      const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
                      int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, void* dlogits_dev,
                      float* update_counter_dev, const void* bias_online_dev, const void* bias_target_dev, void* stream);
+
+/* The same loss with the gradient in its natural, compact form (csrc/learner2.hip): dLoss/dlogits is non-zero only in the
+ * n_atoms atoms of the action each sample took, so instead of a dense [B, A*K] matrix this writes
+ *   dl_dev [B, 64] fp32 (16-byte aligned): dl[b, k] = d mean(td * w) / d online(obs_tm1)[b, act[b], k], zero for k >= n_atoms.
+ * Everything else (inputs, td_dev, w_dev, update_counter_dev, biases) as in hb_c51_loss_grad; the selector's softmax
+ * expectations are spread over all 64 lanes of the sample's wavefront and the batch maximum of the IS weights comes from
+ * the extreme probabilities (x -> x^beta is monotone) instead of B pow calls per sample.                                      */
+int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_dev, int32_t dtype, const int32_t* act_dev,
+                       const float* rew_dev, const float* term_dev, const double* prios_dev, const float* beta_dev,
+                       const float* disc_dev, int32_t mask_terminal, const float* support_dev, int64_t batch, int32_t n_actions,
+                       int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev, float* update_counter_dev,
+                       const void* bias_online_dev, const void* bias_target_dev, void* stream);
+
+/* hb_c51_backward: everything between that loss and the first layer's weight gradient, in ONE launch (the `jax.grad` of
+ * rlax_rainbow.py:203-213 through the output layer and the ReLU of noisy_mlp.py:176-185), from the compact gradient:
+ *   dh_dev  [B, hidden]  (dtype)  = (hidden_dev[b, j] > 0) * sum_k dl[b, k] * w2[j, act[b] * n_atoms + k]
+ *   db1_dev [hidden]     fp32     = column sums of dh_dev as stored
+ *   dw2_dev [hidden, dw2_ld] (dtype): columns a * n_atoms + k = sum over the samples with act == a of hidden[b, j] * dl[b, k]
+ *                                  (zero for an action nobody took; columns >= A * n_atoms are not written)
+ *   db2_dev [A * n_atoms] fp32    = sum over those samples of dl[b, k]
+ * hidden_dev [B, hidden_ld] are the post-ReLU activations of obs_tm1, w2_dev [hidden, w2_ld] the effective output-layer
+ * weights, both in `dtype` (0 f32, 1 bf16, 2 f16). Every sum runs over samples in ascending order: results are
+ * bit-reproducible (no atomics). Replaces two dense GEMMs (dW2, dH), hb_colsum and hb_relu_bwd_colsum.                    */
+int hb_c51_backward(const float* dl_dev, const int32_t* act_dev, const void* hidden_dev, int32_t hidden_ld, const void* w2_dev,
+                    int32_t w2_ld, int32_t dtype, int64_t batch, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* dh_dev,
+                    float* db1_dev, void* dw2_dev, int32_t dw2_ld, float* db2_dev, void* stream);
 
 /* hb_colsum: out_dev[j] = sum_i x[i, j] with fp32 accumulation in a fixed order (bias gradients:
  * the column sums of dLoss/dlogits and of dLoss/dhidden). x_dev [rows, cols] contiguous.        */

@@ -204,6 +204,6 @@ def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, players):
                 "median_top2_gap": float(gap.median())}
     _record(f"actor_{dtype}_{players}p", {"measured": measured, "tolerance": {k: tol[k] for k in ("q_abs", "argmax_gap")}})
     assert measured["q_max_abs_err"] <= tol["q_abs"], measured
-    assert measured["rows_with_clear_gap"] > 0.5, measured
+    assert measured["rows_with_clear_gap"] > 0.3, measured
     assert bool(agree[clear].all()), measured
     assert bool(legal.gather(1, act.long()[:, None]).all())

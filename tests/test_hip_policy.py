@@ -292,6 +292,71 @@ def test_fused_learner_equals_autograd_learner(mask, priority, n_step):
     assert torch.allclose(got[:obs_len], w_eff, rtol=1e-2, atol=1e-3) and not got[obs_len:].any()   # K padding stays zero
 
 
+@pytest.mark.parametrize("shape", [(658, 20, 512), (1280, 48, 512), (171, 11, 32), (658, 20, 40)])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_sparse_backward_equals_dense_chain(shape, dtype):
+    """hb_c51_loss_sparse + hb_c51_backward (csrc/learner2.hip: compact dLoss/dlogits, one launch for dH / db1 / dW2 / db2)
+    against the dense chain they replace (hb_c51_loss_grad + dW2 GEMM + hb_colsum + dH GEMM + hb_relu_bwd_colsum) on the same
+    batch: same td and IS weights; in fp32 the gradients agree to summation order; in bf16 / f16 the sparse path keeps
+    dLoss/dlogits in fp32 where the dense one rounds it, so they agree to that rounding."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    obs_len, n_act, hidden = shape
+    n = 256
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=n, experience_buffer_size=n, mask_terminal=True,
+                               compute_dtype=dtype, layers=[hidden])
+    agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False) for _ in (0, 1)]
+    g = torch.Generator(device="cuda").manual_seed(obs_len)
+    o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    o2 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
+    act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+    act[act == 3] = 2                                                   # action 3 is never taken: its dW2 / db2 slices must be zero
+    rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
+    st = torch.randint(1, 3, (n,), device="cuda", generator=g).to(torch.int8)
+    idx = torch.randperm(n, device="cuda", generator=g)
+    pri = (torch.rand(n, device="cuda", generator=g, dtype=torch.float64) + 0.05) / n
+    for a, sparse in zip(agents, (True, False)):
+        with torch.no_grad():
+            for layer in a.online.layers:
+                layer.b_sigma.fill_(0.05)
+                layer.b.fill_(0.03)
+        a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+        a.add_experience((None, (o2, legal)), act, rew, st)
+        fl = a._fused_learner()
+        fl.refresh_effective()
+        assert fl.sparse_backward
+        fl.sparse_backward = sparse
+        a.experience.sync_size()
+        a._beta.fill_(0.4)
+        fl.part1(idx, pri)
+    s, d = agents[0]._fl, agents[1]._fl
+    AK = n_act * 51
+    assert torch.allclose(s.td, d.td, rtol=1e-5, atol=1e-6) and torch.allclose(s.w_is, d.w_is, rtol=1e-6)
+    assert float(s.step) == float(d.step) == 1.0
+    # compact gradient == the populated slice of the dense one (dense is rounded to the GEMM dtype)
+    ar = torch.arange(n, device="cuda")
+    cols = s.act.long()[:, None] * 51 + torch.arange(51, device="cuda")[None]
+    dense_slice = d.dlogits.float()[ar[:, None], cols]
+    tol = dict(float32=(1e-5, 1e-9), bfloat16=(1e-2, 1e-7), float16=(2e-3, 1e-7))[dtype]
+    assert torch.allclose(s.dl[:, :51], dense_slice, rtol=tol[0], atol=tol[1] + 2e-3 * float(dense_slice.abs().max()) * (dtype != "float32"))
+    assert not s.dl[:, 51:].any()
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    lim = dict(float32=2e-5, bfloat16=2e-2, float16=3e-2)[dtype]        # f16: the dense chain's dlogits go subnormal
+    assert rel(s._gw2_out[:, :AK].float(), d._gw2_out[:, :AK].float()) < lim
+    assert rel(s._gb2_pad[:AK], d._gb2_pad[:AK]) < lim
+    assert rel(s.g_b1, d.g_b1) < lim
+    assert rel(s._gw1_out[:obs_len].float(), d._gw1_out[:obs_len].float()) < lim
+    assert not s._gw2_out[:, 3 * 51:4 * 51].any() and not s._gb2_pad[3 * 51:4 * 51].any()      # the action nobody took
+    # bit-reproducible: a second run of the sparse path gives identical bits
+    keep = [t.clone() for t in (s.dh, s.g_b1, s._gw2_out, s._gb2_pad, s.dl)]
+    s.part1(idx, pri)
+    for x, y in zip(keep, (s.dh, s.g_b1, s._gw2_out, s._gb2_pad, s.dl)):
+        assert torch.equal(x, y)
+
+
 def test_relu_backward_with_column_sums_and_update_counter():
     """hb_relu_bwd_colsum == aten::threshold_backward + column sums (fp32, fixed order); the loss kernel
     advances the learner's step counter exactly once per update."""
