@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/hanabi_hip.h"
@@ -44,18 +45,28 @@ template <> __device__ __forceinline__ float rounded<float>(float v) { return v;
 template <> __device__ __forceinline__ float rounded<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
 template <> __device__ __forceinline__ float rounded<__half>(float v) { return __half2float(__float2half(v)); }
 
-__device__ __forceinline__ float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+// Wave-wide reductions on the DPP data path (no LDS round trips: a ds_bpermute-based __shfl_xor tree costs ~800 cycles per
+// reduction on a lone wavefront, this ~80). quad_perm swaps, row rotations, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 (gfx9 DPP); lane 63 ends up with the total, which is broadcast through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_min(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+#define HB_WAVE_REDUCE(NAME, OP, IDENT)                                                       \
+  __device__ __forceinline__ float NAME(float v) {                                            \
+    v = OP(v, dpp_mov<0xb1, 0xf>(v, v));   /* quad_perm:[1,0,3,2] */                          \
+    v = OP(v, dpp_mov<0x4e, 0xf>(v, v));   /* quad_perm:[2,3,0,1] */                          \
+    v = OP(v, dpp_mov<0x124, 0xf>(v, v));  /* row_ror:4 */                                    \
+    v = OP(v, dpp_mov<0x128, 0xf>(v, v));  /* row_ror:8: every lane holds its row's result */ \
+    v = OP(v, dpp_mov<0x142, 0xa>(IDENT, v));  /* row_bcast:15 -> rows 1, 3 */                \
+    v = OP(v, dpp_mov<0x143, 0xc>(IDENT, v));  /* row_bcast:31 -> rows 2, 3 */                \
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));                  \
+  }
+__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
+HB_WAVE_REDUCE(wave_max, fmaxf, -INFINITY)
+HB_WAVE_REDUCE(wave_min, fminf, INFINITY)
+HB_WAVE_REDUCE(wave_sum, op_add, 0.f)
+#undef HB_WAVE_REDUCE
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -63,6 +74,25 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 constexpr int DL_LD = 64;  // row stride of the compact gradient (K <= 64 atoms, zero padded)
+
+// one logits row (+ its bias) -> LDS as fp32, 16 elements per lane at a time: all 16 (32 with the bias) loads of a round are
+// issued before the first LDS write, so they share one memory round trip
+template <typename T>
+__device__ __forceinline__ void stage_row(const T* __restrict__ row, const T* __restrict__ bias, float* dst, int n, int lane) {
+  for (int base = 0; base < n; base += 1024) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = base + lane + 64 * i;
+      v[i] = e < n ? ld<T>(row, e) + (bias ? ld<T>(bias, e) : 0.f) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = base + lane + 64 * i;
+      if (e < n) dst[e] = v[i];
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // one wavefront (= one workgroup) per sample; A <= 64, K <= 64
@@ -75,17 +105,23 @@ __global__ __launch_bounds__(64) void c51_sparse_kernel(const T* __restrict__ lo
                                                         float* __restrict__ td_out, float* __restrict__ w_out, float* __restrict__ dl,
                                                         float* __restrict__ counter, const T* __restrict__ bias_on,
                                                         const T* __restrict__ bias_t) {
-  extern __shared__ float sel[];  // A*K + 64 floats
+  extern __shared__ float sel[];  // A*K floats: the selector's logits; 64: the support
   const int lane = threadIdx.x, b = blockIdx.x;
   if (counter && b == 0 && lane == 0) *counter += 1.f;  // nothing else touches it during this kernel
   const int AK = A * K;
-  // ---- the loads that nothing depends on go first: selector row (online net on obs_t), action, reward, discount
-  const T* row_sel = logits_on + static_cast<long long>(B + b) * rs;
-  for (int e = lane; e < AK; e += 64) sel[e] = ld<T>(row_sel, e) + (bias_on ? ld<T>(bias_on, e) : 0.f);
+  // ---- every global load of the kernel is issued up front, the per-sample scalars first (the action indexes the last one)
   const int a_tm1 = act[b];
   const float r_b = rew[b];
   float gamma = disc[b];
   if (mask_terminal) gamma *= 1.f - term[b];
+  const bool atom = lane < K;
+  const T* row_sel = logits_on + static_cast<long long>(B + b) * rs;     // online net on obs_t: the double-Q selector
+  stage_row<T>(row_sel, bias_on, sel, AK, lane);
+  float* ssup = sel + AK;
+  ssup[lane] = lane < K ? support[lane] : 0.f;
+  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * rs + a_tm1 * K + lane) +
+                              (bias_on ? ld<T>(bias_on, a_tm1 * K + lane) : 0.f)
+                        : -INFINITY;
   // ---- importance weight ((1/P).astype(f32)) ** beta / max over the batch (rlax_rainbow.py:188-189). x -> x ** beta is
   // monotone, so the maximum is attained at the smallest (beta > 0) or largest (beta < 0) probability: two pow calls
   // instead of B per wavefront
@@ -98,7 +134,7 @@ __global__ __launch_bounds__(64) void c51_sparse_kernel(const T* __restrict__ lo
   }
   ipmin = wave_min(ipmin);
   ipmax = wave_max(ipmax);
-  const float wmax = fmaxf(powf(ipmin, beta), powf(ipmax, beta));
+  const float wmax = powf(beta >= 0.f ? ipmax : ipmin, beta);
   const float w_b = powf(static_cast<float>(1.0 / prios[b]), beta) / wmax;
   wave_fence();
   // ---- double-Q selector: q_sel[a] = mean(softmax(online(obs_t))[a] * z) (no legal mask, as the reference). S lanes share
@@ -118,7 +154,7 @@ __global__ __launch_bounds__(64) void c51_sparse_kernel(const T* __restrict__ lo
     for (int k = k0; k < k1; ++k) {
       const float e = __expf(r[k] - ma);
       s += e;
-      t += e * support[k];
+      t += e * ssup[k];
     }
   float sa = 0.f, ta = 0.f;
   for (int i = 0; i < S; ++i) {  // fixed order: part 0, 1, 2
@@ -130,20 +166,16 @@ __global__ __launch_bounds__(64) void c51_sparse_kernel(const T* __restrict__ lo
   const unsigned long long hit = __ballot(on && part == 0 && q == qbest);
   const int a_star = (__ffsll(static_cast<long long>(hit)) - 1) / S;  // lowest action index among ties, like argmax
   // ---- target distribution p = softmax(target(obs_t)[a*]) and its projection onto the support
-  const bool atom = lane < K;
+  // (staging the whole target row in LDS beside the selector's, to avoid this dependent load, measured slower: 12.8 vs 10.6 us)
   const float lt = atom ? ld<T>(logits_t, static_cast<long long>(b) * rs + a_star * K + lane) +
                               (bias_t ? ld<T>(bias_t, a_star * K + lane) : 0.f)
-                        : -INFINITY;
-  // (issued here so its latency hides under the projection loop)
-  const float l1 = atom ? ld<T>(logits_on, static_cast<long long>(b) * rs + a_tm1 * K + lane) +
-                              (bias_on ? ld<T>(bias_on, a_tm1 * K + lane) : 0.f)
                         : -INFINITY;
   const float mt = wave_max(lt);
   const float et = atom ? __expf(lt - mt) : 0.f;
   const float p = et / wave_sum(et);
-  const float vmin = support[0], vmax = support[K - 1];
+  const float vmin = ssup[0], vmax = ssup[K - 1];
   const float delta = (vmax - vmin) / static_cast<float>(K - 1);
-  const float zi = atom ? support[lane] : 0.f;
+  const float zi = ssup[lane];
   const float tz = fminf(fmaxf(r_b + gamma * zi, vmin), vmax);  // clipped r + gamma * z_j held by lane j
   float target = 0.f;
   const float inv_delta = 1.f / delta;
@@ -179,141 +211,239 @@ struct BwdArgs {
   float* db2;             // out [A*K]
   int B, H, A, K, h_ld, w2_ld, dw2_ld;
   int n_dh_tiles;         // workgroups [0, n_dh_tiles): dH tiles of JT hidden units; the rest: (action, 64-unit tile) of dW2
+  int block_offset;       // added to blockIdx.x (0; measurements launch the two halves separately)
 };
 
+constexpr int BWD_T = 1024;  // threads per workgroup of the backward kernel (16 wavefronts)
+
 template <typename T, int JT>
-__global__ __launch_bounds__(256) void c51_backward_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_cnt[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* h = static_cast<const T*>(a.h);
-  if (static_cast<int>(blockIdx.x) < a.n_dh_tiles) {
+  const int blk = static_cast<int>(blockIdx.x) + a.block_offset;
+  if (blk < a.n_dh_tiles) {
     // ---- dH tile: hidden units j0 .. j0 + JT - 1 for every sample. The JT rows of W2 sit in LDS, every action's K atoms
-    // in a slot of its own: 64 elements (k >= K zero, where dl is zero too) + padding to SLOT elements, chosen so that the
-    // 16-byte reads of lanes that took different actions fall on different banks (72 x 2 B: bank offsets a * 36 mod 64,
-    // 68 x 4 B: a * 4 mod 64 — all distinct multiples of 4 for 16 consecutive actions)
+    // in a slot of its own: 64 elements (k >= K zero, where dl is zero too) + padding to SLOT elements, so that 16-byte reads
+    // of lanes whose samples took different actions spread over the banks (72 x 2 B: bank offsets a * 36 mod 64; 68 x 4 B:
+    // a * 4 mod 64). FOUR lanes share one sample: lane part p multiplies the 16-byte chunks p, p + 4, ... of the 64-wide
+    // dot product and the four partial sums are combined on the DPP path ((p0 + p1) + (p2 + p3): a fixed order).
     constexpr int SLOT = sizeof(T) == 2 ? 72 : 68;
     constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte read
-    const int j0 = static_cast<int>(blockIdx.x) * JT;
+    constexpr int NCH = DL_LD / VEC;               // chunks of the dot product: 8 (16-bit) or 16 (fp32)
+    constexpr int CPP = NCH / 4;                   // chunks per lane part
+    const int j0 = blk * JT;
     const int ld_w = a.A * SLOT;
     T* w2s = reinterpret_cast<T*>(smem);
-    float* red = reinterpret_cast<float*>(smem + static_cast<size_t>(JT) * ld_w * sizeof(T));  // [4][JT]
+    float* red = reinterpret_cast<float*>(smem + static_cast<size_t>(JT) * ld_w * sizeof(T));  // [16][JT]
     const T* w2 = static_cast<const T*>(a.w2);
-    for (int e = tid; e < JT * ld_w; e += 256) {
-      const int jj = e / ld_w, c = e - jj * ld_w;
-      const int ac = c / SLOT, k = c - ac * SLOT;
-      float v = 0.f;
-      if (k < a.K && j0 + jj < a.H) v = ld<T>(w2, static_cast<long long>(j0 + jj) * a.w2_ld + ac * a.K + k);
-      st<T>(w2s, e, v);
+    // this lane's sample of the first round: action, its chunks of dl, the JT hidden activations. Requested BEFORE the tile is
+    // filled, so the two memory round trips overlap
+    const int part = tid & 3;
+    constexpr bool VEC_IO = JT * sizeof(T) == 16;
+    const bool vec = VEC_IO && j0 + JT <= a.H && ((a.h_ld | a.H) & (JT - 1)) == 0;
+    float dlv[CPP][VEC];
+    T hin[JT];
+    int c0 = 0;
+    auto load_sample = [&](int base) {
+      const int b = base + (tid >> 2);
+      const int bb = b < a.B ? b : a.B - 1;
+#pragma unroll
+      for (int u = 0; u < CPP; ++u) {
+        const float4* dlp = reinterpret_cast<const float4*>(a.dl + static_cast<long long>(bb) * DL_LD + (part + 4 * u) * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) {
+          const float4 v = dlp[i];
+          dlv[u][4 * i] = v.x; dlv[u][4 * i + 1] = v.y; dlv[u][4 * i + 2] = v.z; dlv[u][4 * i + 3] = v.w;
+        }
+      }
+      c0 = a.act[bb] * SLOT;
+      if (vec) {
+        *reinterpret_cast<uint4*>(hin) = *reinterpret_cast<const uint4*>(h + static_cast<long long>(bb) * a.h_ld + j0);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) hin[jj] = j0 + jj < a.H ? h[static_cast<long long>(bb) * a.h_ld + j0 + jj] : static_cast<T>(0.f);
+      }
+    };
+    load_sample(0);
+    // fill: zero the whole tile (slot padding, atoms k >= K), then scatter the JT rows. No integer division (c / K through an
+    // exact float reciprocal for c < 4096) and every global load independent of the others, so they are all in flight together
+    for (int e = tid; e < JT * ld_w * static_cast<int>(sizeof(T)) / 16; e += BWD_T) reinterpret_cast<uint4*>(smem)[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {
+      const int AK = a.A * a.K;
+      const float inv_k = 1.0f / static_cast<float>(a.K);
+#pragma unroll
+      for (int jj = 0; jj < JT; ++jj) {
+        if (j0 + jj < a.H) {
+          const T* src = w2 + static_cast<long long>(j0 + jj) * a.w2_ld;
+          for (int c = tid; c < AK; c += BWD_T) {
+            const int ac = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_k);
+            w2s[jj * ld_w + ac * SLOT + (c - ac * a.K)] = src[c];
+          }
+        }
+      }
     }
     __syncthreads();
+    const int kc = (a.K + VEC - 1) / VEC;          // 16-byte chunks that hold atoms (7 of 8 for 51 bf16 atoms)
     float colsum[JT];
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) colsum[jj] = 0.f;
     T* dh = static_cast<T*>(a.dh);
-    const int kc = (a.K + VEC - 1) / VEC;          // 16-byte chunks that hold atoms (7 of 8 for 51 bf16 atoms)
-    for (int b = tid; b < a.B; b += 256) {         // ascending sample order per thread: fixed summation order
-      float dlv[DL_LD];
-      const float4* dlp = reinterpret_cast<const float4*>(a.dl + static_cast<long long>(b) * DL_LD);
-#pragma unroll
-      for (int i = 0; i < DL_LD / 4; ++i) {
-        const float4 v = dlp[i];
-        dlv[4 * i] = v.x; dlv[4 * i + 1] = v.y; dlv[4 * i + 2] = v.z; dlv[4 * i + 3] = v.w;
-      }
-      const int c0 = a.act[b] * SLOT;
+    for (int base = 0; base < a.B; base += BWD_T / 4) {   // ascending sample order per lane: fixed summation order
+      const int b = base + (tid >> 2);
+      const bool live = b < a.B;
+      if (base > 0) load_sample(base);
+      T gout[JT];
 #pragma unroll
       for (int jj = 0; jj < JT; ++jj) {
         const uint4* wr = reinterpret_cast<const uint4*>(w2s + jj * ld_w + c0);
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < DL_LD / VEC; ++c) {
-          if (c < kc) {                            // wave-uniform
-            const uint4 u = wr[c];
-            const uint32_t d[4] = {u.x, u.y, u.z, u.w};
+        for (int u = 0; u < CPP; ++u) {
+          const int c = part + 4 * u;
+          if (c < kc) {
+            const uint4 q = wr[c];
+            const uint32_t d[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               if constexpr (sizeof(T) == 4) {
-                acc = fmaf(dlv[c * 4 + i], __uint_as_float(d[i]), acc);
+                acc = fmaf(dlv[u][i], __uint_as_float(d[i]), acc);
               } else if constexpr (std::is_same<T, __hip_bfloat16>::value) {
-                acc = fmaf(dlv[c * 8 + 2 * i], __uint_as_float(d[i] << 16), acc);
-                acc = fmaf(dlv[c * 8 + 2 * i + 1], __uint_as_float(d[i] & 0xFFFF0000u), acc);
+                acc = fmaf(dlv[u][2 * i], __uint_as_float(d[i] << 16), acc);
+                acc = fmaf(dlv[u][2 * i + 1], __uint_as_float(d[i] & 0xFFFF0000u), acc);
               } else {
                 const __half2 hh = *reinterpret_cast<const __half2*>(&d[i]);
-                acc = fmaf(dlv[c * 8 + 2 * i], __low2float(hh), acc);
-                acc = fmaf(dlv[c * 8 + 2 * i + 1], __high2float(hh), acc);
+                acc = fmaf(dlv[u][2 * i], __low2float(hh), acc);
+                acc = fmaf(dlv[u][2 * i + 1], __high2float(hh), acc);
               }
             }
           }
         }
-        if (j0 + jj < a.H) {
-          const long long o = static_cast<long long>(b) * a.H + j0 + jj;
-          const float g = ld<T>(h, static_cast<long long>(b) * a.h_ld + j0 + jj) > 0.f ? acc : 0.f;
-          st<T>(dh, o, g);
-          colsum[jj] += rounded<T>(g);             // the column sum of dH as it is stored
+        acc += dpp_mov<0xb1, 0xf>(acc, acc);      // parts (0,1) and (2,3)
+        acc += dpp_mov<0x4e, 0xf>(acc, acc);      // ... and the two pairs: every lane of the quad holds the dot product
+        const float g = ld<T>(hin, jj) > 0.f ? acc : 0.f;
+        st<T>(gout, jj, g);
+        if (live && part == 0 && j0 + jj < a.H) colsum[jj] += rounded<T>(g);   // the column sum of dH as it is stored
+      }
+      if (live && part == 0) {
+        if (vec) {
+          *reinterpret_cast<uint4*>(dh + static_cast<long long>(b) * a.H + j0) = *reinterpret_cast<const uint4*>(gout);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < JT; ++jj)
+            if (j0 + jj < a.H) dh[static_cast<long long>(b) * a.H + j0 + jj] = gout[jj];
         }
       }
     }
-    // db1: threads -> waves (shuffle tree) -> workgroup (fixed order 0..3)
+    // db1: lanes -> wavefront (DPP tree) -> workgroup (wavefronts 0..15 in order)
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
       const float v = wave_sum(colsum[jj]);
       if (lane == 0) red[wave * JT + jj] = v;
     }
     __syncthreads();
-    if (tid < JT && j0 + tid < a.H) a.db1[j0 + tid] = ((red[tid] + red[JT + tid]) + red[2 * JT + tid]) + red[3 * JT + tid];
+    if (tid < JT && j0 + tid < a.H) {
+      float t = 0.f;
+      for (int w = 0; w < BWD_T / 64; ++w) t += red[w * JT + tid];
+      a.db1[j0 + tid] = t;
+    }
     return;
   }
   // ---- dW2 / db2 of one action for 64 hidden units: the samples that took this action, in ascending order
-  const int id = static_cast<int>(blockIdx.x) - a.n_dh_tiles;
+  const int id = blk - a.n_dh_tiles;
   const int n_jt = (a.H + 63) / 64;
   const int act_id = id / n_jt, j0 = (id - act_id * n_jt) * 64;
   int* list = reinterpret_cast<int*>(smem);          // up to B sample indices
-  __shared__ int wave_cnt[4];
-  __shared__ int total;
-  int n_list = 0;
-  for (int base = 0; base < a.B; base += 256) {      // (B = 256: one round)
+  int n = 0;
+  for (int base = 0; base < a.B; base += BWD_T) {
     const int b = base + tid;
     const bool mine = b < a.B && a.act[b] == act_id;
     const unsigned long long mk = __ballot(mine);
     if (lane == 0) wave_cnt[wave] = __popcll(mk);
     __syncthreads();
-    int off = n_list;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    int off = n, all = 0;
+    for (int w = 0; w < BWD_T / 64; ++w) {
+      if (w < wave) off += wave_cnt[w];
+      all += wave_cnt[w];
+    }
     if (mine) list[off + __popcll(mk & ((1ull << lane) - 1ull))] = b;
-    n_list += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    n += all;
     __syncthreads();
   }
-  if (tid == 0) total = n_list;
+  // The samples of this action are split into 8 contiguous ranges (ascending), each handled by a PAIR of wavefronts (one per
+  // half of the atoms): thread -> (hidden unit j0 + lane, atom half kh, sample range sq) accumulates 32 atoms over its range;
+  // the 8 partial sums of every output are then added in range order through LDS. However many of the batch's samples took
+  // this action (a greedy policy concentrates them on one), no thread walks more than n / 8 of them.
+  const int kh = wave & 1, sq = wave >> 1;
+  const int j = j0 + lane;
+  const int per = (n + 7) >> 3;
+  const int s_begin = sq * per, s_end = s_begin + per < n ? s_begin + per : n;
+  // One memory round trip for everything the accumulation needs: this lane's hidden activations of its (at most 32) samples
+  // into registers, and the dl rows of ALL the action's samples into LDS (every thread a few independent 16-byte loads)
+  float* dls = reinterpret_cast<float*>(smem) + a.B;    // [n][64] behind the list
+  float hreg[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const bool ok = s_begin + u < s_end;
+    const int b = list[ok ? s_begin + u : 0];
+    hreg[u] = (ok && j < a.H) ? ld<T>(h, static_cast<long long>(b) * a.h_ld + j) : 0.f;
+  }
+  for (int e = tid; e < n * 16; e += BWD_T)
+    reinterpret_cast<float4*>(dls)[e] = reinterpret_cast<const float4*>(a.dl + static_cast<long long>(list[e >> 4]) * DL_LD)[e & 15];
   __syncthreads();
-  const int n = total;
-  // thread -> (hidden unit jj = lane, 16 atoms kq*16 .. +15); lanes of a wave share the atoms (broadcast loads of dl)
-  const int jj = lane, kq = wave;
-  const int j = j0 + jj;
-  float acc[16];
+  float acc[32];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int s = 0; s < n; ++s) {
-    const int b = list[s];
-    const float hv = j < a.H ? static_cast<float>(h[static_cast<long long>(b) * a.h_ld + j]) : 0.f;
-    const float4* dlp = reinterpret_cast<const float4*>(a.dl + static_cast<long long>(b) * DL_LD + kq * 16);
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  float dsum = 0.f;  // db2: atom kh * 32 + lane (lanes < 32), summed over the range
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 v = dlp[i];
-      acc[4 * i] = fmaf(hv, v.x, acc[4 * i]);
-      acc[4 * i + 1] = fmaf(hv, v.y, acc[4 * i + 1]);
-      acc[4 * i + 2] = fmaf(hv, v.z, acc[4 * i + 2]);
-      acc[4 * i + 3] = fmaf(hv, v.w, acc[4 * i + 3]);
+  for (int u = 0; u < 32; ++u) {
+    if (s_begin + u < s_end) {                            // wave-uniform
+      const float* dlp = dls + (s_begin + u) * DL_LD + kh * 32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 d = reinterpret_cast<const float4*>(dlp)[i];   // the same address in every lane: a broadcast read
+        acc[4 * i] = fmaf(hreg[u], d.x, acc[4 * i]);
+        acc[4 * i + 1] = fmaf(hreg[u], d.y, acc[4 * i + 1]);
+        acc[4 * i + 2] = fmaf(hreg[u], d.z, acc[4 * i + 2]);
+        acc[4 * i + 3] = fmaf(hreg[u], d.w, acc[4 * i + 3]);
+      }
+      dsum += lane < 32 ? dlp[lane & 31] : 0.f;
     }
   }
-  if (j < a.H) {
-    T* out = static_cast<T*>(a.dw2) + static_cast<long long>(j) * a.dw2_ld + act_id * a.K + kq * 16;
+  constexpr int RLD = 20;                               // floats per (range, hidden unit) row: 16 atoms + pad (80 B)
+  float* red = dls + static_cast<size_t>(a.B) * DL_LD;  // [8][64][RLD] behind the staged dl rows
+  float* red2 = red + 8 * 64 * RLD;                     // [8][64]: db2 partials
+  T* dw2 = static_cast<T*>(a.dw2);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (kq * 16 + i < a.K) st<T>(out, i, acc[i]);
+  for (int p = 0; p < 4; ++p) {                         // 16 atoms per pass: 16 p .. 16 p + 15 (atom half p >> 1)
+    if (kh == (p >> 1)) {
+      float4* dst = reinterpret_cast<float4*>(red + (sq * 64 + lane) * RLD);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dst[i] = make_float4(acc[(p & 1) * 16 + 4 * i], acc[(p & 1) * 16 + 4 * i + 1], acc[(p & 1) * 16 + 4 * i + 2],
+                             acc[(p & 1) * 16 + 4 * i + 3]);
+    }
+    __syncthreads();
+    {
+      const int i = tid & 15, jj = tid >> 4, k = 16 * p + i;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[(r * 64 + jj) * RLD + i];
+      if (k < a.K && j0 + jj < a.H) st<T>(dw2, static_cast<long long>(j0 + jj) * a.dw2_ld + act_id * a.K + k, t);
+    }
+    __syncthreads();
   }
-  if (j0 == 0 && tid < a.K) {  // db2 slice: one thread per atom
-    float sum = 0.f;
-    for (int s = 0; s < n; ++s) sum += a.dl[static_cast<long long>(list[s]) * DL_LD + tid];
-    a.db2[act_id * a.K + tid] = sum;
+  if (j0 == 0) {
+    if (lane < 32) red2[sq * 64 + kh * 32 + lane] = dsum;
+    __syncthreads();
+    if (tid < a.K) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red2[r * 64 + tid];
+      a.db2[act_id * a.K + tid] = t;
+    }
   }
 }
 
@@ -325,13 +455,20 @@ int launch_backward(const BwdArgs& a0, hipStream_t s) {
   const size_t list_bytes = static_cast<size_t>(a.B) * 4;
   // hidden units per dH tile: 8 (64 workgroups for 512 units; bf16, 20 actions: 23 KB of LDS), fewer if LDS is short
   int jt = 8;
-  while (jt > 1 && jt * row + 4 * jt * 4 > 64 * 1024) jt >>= 1;
+  while (jt > 1 && jt * row + 16 * jt * 4 > 64 * 1024) jt >>= 1;
   a.n_dh_tiles = (a.H + jt - 1) / jt;
-  const unsigned blocks = static_cast<unsigned>(a.n_dh_tiles + a.A * n_jt);
-  size_t lds = jt * row + 4 * jt * 4;
+  unsigned blocks = static_cast<unsigned>(a.n_dh_tiles + a.A * n_jt);
+  if (const char* part = getenv("HB_BWD_PART")) {  // measurement aid: "1" = only the dH tiles, "2" = only the dW2 / db2 tiles
+    if (part[0] == '1') blocks = static_cast<unsigned>(a.n_dh_tiles);
+    if (part[0] == '2') { a.block_offset = a.n_dh_tiles; blocks = static_cast<unsigned>(a.A * n_jt); }
+  }
+  size_t lds = jt * row + 16 * jt * 4;
   if (lds < list_bytes) lds = list_bytes;
+  // the dW2 / db2 half: sample list, the staged dl rows of up to B samples, the reduction buffers
+  const size_t dw2_bytes = list_bytes + static_cast<size_t>(a.B) * DL_LD * 4 + (8 * 64 * 20 + 8 * 64) * sizeof(float);
+  if (lds < dw2_bytes) lds = dw2_bytes;
   if (lds > 150 * 1024) return fail(HB_ERR_INVALID, "batch / output layer too large for the backward kernel's LDS tile");
-#define HB_BWD(JT) hipLaunchKernelGGL((c51_backward_kernel<T, JT>), dim3(blocks), dim3(256), lds, s, a)
+#define HB_BWD(JT) hipLaunchKernelGGL((c51_backward_kernel<T, JT>), dim3(blocks), dim3(BWD_T), lds, s, a)
   if (jt == 8) HB_BWD(8);
   else if (jt == 4) HB_BWD(4);
   else if (jt == 2) HB_BWD(2);
@@ -381,12 +518,12 @@ int hb_c51_backward(const float* dl_dev, const int32_t* act_dev, const void* hid
     return fail(HB_ERR_INVALID, "null argument");
   if (n_actions < 1 || n_actions > 64 || n_atoms < 2 || n_atoms > 64) return fail(HB_ERR_INVALID, "need n_actions <= 64 and 2 <= n_atoms <= 64");
   if (batch <= 0) return HB_OK;
-  if (batch > 16384) return fail(HB_ERR_INVALID, "batch must be <= 16384");
+  if (batch > 256) return fail(HB_ERR_INVALID, "batch must be <= 256 (a thread keeps its share of one action's samples in 32 registers)");
   const int AK = n_actions * n_atoms;
   if (hidden < 1 || hidden_ld < hidden || w2_ld < AK || dw2_ld < AK) return fail(HB_ERR_INVALID, "bad hidden size / row strides");
   if (reinterpret_cast<uintptr_t>(dl_dev) & 15u) return fail(HB_ERR_ALIGN, "dl_dev must be 16-byte aligned");
   BwdArgs a{dl_dev, act_dev, hidden_dev, w2_dev, dh_dev, db1_dev, dw2_dev, db2_dev, static_cast<int>(batch), hidden, n_actions,
-            n_atoms, hidden_ld, w2_ld, dw2_ld, 0};
+            n_atoms, hidden_ld, w2_ld, dw2_ld, 0, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == 0) rc = launch_backward<float>(a, s);

@@ -92,7 +92,7 @@ class FusedLearner:
         self.dlogits = torch.zeros(B, self.Np, dtype=self.cd, device=dev)   # dense dLoss/dlogits (sparse_backward False only)
         self.dl = torch.zeros(B, 64, **f32)                                # compact dLoss/dlogits: the K atoms of the taken action
         self.dh = torch.zeros(B, H, dtype=self.cd, device=dev)
-        self.sparse_backward = self.Kk <= 64 and self.A <= 64
+        self.sparse_backward = self.Kk <= 64 and self.A <= 64 and B <= 256   # (else: the dense chain below)
         self.AK = AK
         self.support = agent.atoms[0].contiguous()
         self._gb2_pad = torch.zeros(self.Np, **f32)

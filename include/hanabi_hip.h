@@ -380,7 +380,7 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
  *                                  (zero for an action nobody took; columns >= A * n_atoms are not written)
  *   db2_dev [A * n_atoms] fp32    = sum over those samples of dl[b, k]
  * hidden_dev [B, hidden_ld] are the post-ReLU activations of obs_tm1, w2_dev [hidden, w2_ld] the effective output-layer
- * weights, both in `dtype` (0 f32, 1 bf16, 2 f16). Every sum runs over samples in ascending order: results are
+ * weights, both in `dtype` (0 f32, 1 bf16, 2 f16); batch <= 256. Every sum runs over samples in ascending order: results are
  * bit-reproducible (no atomics). Replaces two dense GEMMs (dW2, dH), hb_colsum and hb_relu_bwd_colsum.                    */
 int hb_c51_backward(const float* dl_dev, const int32_t* act_dev, const void* hidden_dev, int32_t hidden_ld, const void* w2_dev,
                     int32_t w2_ld, int32_t dtype, int64_t batch, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* dh_dev,

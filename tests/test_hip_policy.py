@@ -314,6 +314,8 @@ def test_sparse_backward_equals_dense_chain(shape, dtype):
     legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
     act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
     act[act == 3] = 2                                                   # action 3 is never taken: its dW2 / db2 slices must be zero
+    if hidden == 512:
+        act[:200] = 7                                                   # a greedy policy: most of the batch took ONE action
     rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
     st = torch.randint(1, 3, (n,), device="cuda", generator=g).to(torch.int8)
     idx = torch.randperm(n, device="cuda", generator=g)
