@@ -128,8 +128,18 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
-  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  // Workgroup -> (row tile, column tile). Workgroups are dealt round-robin over the 8 XCDs in launch order (speed only, never
+  // correctness): linear id L runs on the XCD labelled L % 8, in the order L / 8. All column tiles of one row tile are given
+  // consecutive slots of ONE label, so that the row tile's activations are fetched into that XCD's L2 once and the other
+  // column tiles hit there (hb_actor_q: 4 column groups re-read the same 256 x 512 hidden activations).
+  int rt = static_cast<int>(blockIdx.x), ct = static_cast<int>(blockIdx.y);
+  if ((gridDim.x & 7u) == 0) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, label = lin & 7u, slot = lin >> 3;
+    ct = static_cast<int>(slot % gridDim.y);
+    rt = static_cast<int>((slot / gridDim.y) * 8u + label);
+  }
+  const long long row0 = static_cast<long long>(rt) * BM;
+  const int col0 = ct * BN;
   const int kt_n = a.k_pad / BK;
 
   // ---- staging: thread owns 16-byte chunk (r, c) of rows r = (tid >> 3) + 64 i, i = 0..3, for both operands
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
   } else {
     // C51 expectation per (row, action) from the bf16 logits tile (the arithmetic of policy_kernel, policy.hip)
     const int K = a.n_atoms;
-    const int first_action = static_cast<int>(blockIdx.y) * a.group_actions;
+    const int first_action = ct * a.group_actions;
     int ga = a.n_actions - first_action;
     if (ga > a.group_actions) ga = a.group_actions;
     for (int id = tid; id < BM * ga; id += NT) {

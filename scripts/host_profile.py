@@ -8,8 +8,8 @@ from hanabi_hip.selfplay import SelfPlaySession
 
 n = 32768
 flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
-env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=1234)
-params = RlaxRainbowParams(compute_dtype="bfloat16", mask_terminal=True)
+env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=1234, packed=True)
+params = RlaxRainbowParams(compute_dtype="bfloat16", mask_terminal=True, packed_obs=True)
 agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s), device="cuda") for s in (0, 1)]
 sess = SelfPlaySession(env, agents)
 for _ in range(60):
@@ -22,4 +22,4 @@ for _ in range(400):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(28)
+st.sort_stats("cumulative").print_stats(45)
