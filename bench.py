@@ -47,11 +47,21 @@ MFMA_PEAK_TFLOPS = {"float32": 157.3, "bfloat16": 2500.0, "float16": 2500.0}
 
 
 def parse():
+    args = _parse()
+    if args.games is None:
+        args.games = 4096 if args.vanilla else 32768
+    return args
+
+
+def _parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--games", type=int, default=32768, help="games per GPU")
+    ap.add_argument("--games", type=int, default=None, help="games per GPU (default 32 768; 4 096 with --vanilla)")
+    ap.add_argument("--vanilla", action="store_true",
+                    help="BASELINE configs[1]: vanilla double-DQN (scalar Q head, rlax_dqn.py:170-205 spec) with uniform replay, "
+                         "4 096 games per GPU")
     ap.add_argument("--players", type=int, default=2)
     ap.add_argument("--updates-per-step", type=int, default=1)
     ap.add_argument("--compute-dtype", default="bfloat16", choices=list(MFMA_PEAK_TFLOPS))
@@ -299,6 +309,8 @@ def main():
     main_stream = None
     if not args.env_only:
         params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=env.packed)
+        if args.vanilla:
+            params = params._replace(distributional=False, use_priority=False)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
                            params._replace(seed=1234 + 17 * s), device=device) for s in range(args.players)]
         for a in agents:
@@ -383,7 +395,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (("2-player full Hanabi, 32 768 envs, Rainbow (PER sum_tree + noisy C51) on 1 MI355X"
-                          if (n == 32768 and args.players == 2) else f"{args.players}-player full Hanabi, {n} envs per GPU")
+                          if (n == 32768 and args.players == 2 and not args.vanilla) else
+                          "2-player full Hanabi, 4 096 parallel envs, vanilla DQN (uniform replay) on 1 MI355X"
+                          if (n == 4096 and args.players == 2 and args.vanilla) else
+                          f"{args.players}-player full Hanabi, {n} envs per GPU" + (", vanilla DQN (uniform replay)" if args.vanilla else ", Rainbow"))
                          + (f" x {world} GPUs (weak scaling: the same per GPU)" if world > 1 else "")),
             "games_per_gpu": n, "players": args.players, "train_batch": 256, "updates_per_step": args.updates_per_step,
             "policy": "random-legal (env only)" if args.env_only else "agent eps-greedy (eps 0.1)",
@@ -470,7 +485,10 @@ def qnet_roofline(agent, env, args):
     executes half of the forward matrix FLOPs."""
     n = env.n
     hidden = agent.params.layers[0]
-    fwd_flop = 4.0 * (env.obs_len * hidden + hidden * env.num_actions * agent.params.n_atoms)  # per sample
+    if agent.distributional:
+        fwd_flop = 4.0 * (env.obs_len * hidden + hidden * env.num_actions * agent.params.n_atoms)  # per sample
+    else:  # vanilla scalar head: one GEMM per layer (SURVEY §8(d): 0.69 MFLOP per sample for 2 players)
+        fwd_flop = 2.0 * (env.obs_len * hidden + hidden * env.num_actions)
     obs = (None, (env.net_obs, env.legal))
     for _ in range(3):
         agent.explore(obs)
@@ -528,12 +546,18 @@ def qnet_roofline(agent, env, args):
     mfma_actor = fl is not None and fl.actor is not None and agent.use_mfma_actor
     kp = -(-env.obs_len // 64) * 64
     ncols = fl.actor.w2t.shape[0] if mfma_actor else -(-env.num_actions * agent.params.n_atoms // 64) * 64
+    if not agent.distributional:
+        ncols = env.num_actions
     exec_flop = 2.0 * (kp * hidden + hidden * ncols)
     exec_tf = exec_flop * n / actor_s / 1e12
     learn_tf = 5.0 * 256 * fwd_flop / learn_s / 1e12
     # learner: 3 forward passes of B rows (online on obs_tm1 and obs_t, target on obs_t; the merged layer-1 GEMM also computes
     # the unused target half of obs_tm1) + backward (dW2, dH, dW1) on the merged weights
-    learn_exec_flop = 256 * (3 * exec_flop + 2.0 * (2 * hidden * ncols + kp * hidden))
+    if fl is not None and getattr(fl, "sparse_backward", False):
+        # sparse backward (csrc/learner2.hip): dH and dW2 touch only the K atoms of the action taken; dW1 stays a dense GEMM
+        learn_exec_flop = 256 * (3 * exec_flop + 2.0 * (2 * hidden * 64 + kp * hidden))
+    else:
+        learn_exec_flop = 256 * (3 * exec_flop + 2.0 * (2 * hidden * ncols + kp * hidden))
     learn_exec_tf = learn_exec_flop / learn_s / 1e12
     # `achieved` / `frac` price the FLOPs the kernels EXECUTE (merged weights: one GEMM per layer); the literal two-GEMM
     # count of SURVEY §8(d) stays beside them as algorithmic_*
@@ -542,7 +566,8 @@ def qnet_roofline(agent, env, args):
                               "frac": exec_tf / peak, "algorithmic_gflop": fwd_flop * n / 1e9, "algorithmic_achieved": actor_tf,
                               "algorithmic_frac": actor_tf / peak,
                               "kernels": ("hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
-                                          if mfma_actor else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act"),
+                                          if mfma_actor else "hb_actor_hidden (MFMA) + library GEMM [N,H]x[H,A] + hb_policy_select"
+                                          if getattr(agent, "_plain_fast", False) else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act"),
                               "per_kernel": per_kernel},
             "learner_update": {"batch": 256, "executed_gflop": learn_exec_flop / 1e9, "ms": learn_s * 1e3,
                                "achieved": learn_exec_tf, "frac": learn_exec_tf / peak,

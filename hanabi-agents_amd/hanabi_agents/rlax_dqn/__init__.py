@@ -1,5 +1,6 @@
 """MI355X-native `hanabi_agents.rlax_dqn`: same public names as the reference package
 (hanabi_agents/rlax_dqn/__init__.py:2-3) plus the replay / network building blocks."""
+from . import bitpack
 from .experience_buffer import ExperienceBuffer
 from .noisy_mlp import NoisyLinear, NoisyMLP
 from .params import RlaxRainbowParams

@@ -178,6 +178,12 @@ class DQNAgent:
         self._last_loss = None
         # fused HIP actor tail / replay insert (hanabi_hip.ops) on the GPU; plain torch ops elsewhere
         self._fused = self.device.type == "cuda" and self.distributional
+        # scalar-Q net (BASELINE config 2) on the GPU with bf16 GEMM inputs and one hidden layer: the hidden layer runs on the same
+        # hand-written MFMA kernel as the C51 actor, the tiny [N, H] x [H, A] output layer on the library GEMM, the selection on
+        # hb_policy_select
+        self._plain_fast = (self.device.type == "cuda" and not self.distributional and params.compute_dtype == "bfloat16"
+                            and len(params.layers) == 1 and params.layers[0] % 256 == 0)
+        self._plain_actor = None
         self._eff_cache = None      # effective (merged) weights of the online net in the GEMM dtype
         self._trg_cache = None      # same for the target net (refreshed in place at every target sync)
         self._x_act = None          # persistent (padded) first-GEMM operand of the actor
@@ -237,6 +243,46 @@ class DQNAgent:
             self._eff_cache = [tuple(t.to(cd).contiguous() for t in layer.effective()) for layer in self.online.layers]
         return self._eff_cache
 
+    def _act_plain(self, obs, legal, epsilon):
+        """Vanilla double-DQN head (rlax_dqn.py:26-33 MLP): q = relu(obs @ W1 + b1) @ W2 + b2, illegal moves masked, epsilon-greedy."""
+        from hanabi_hip import _capi as K
+        from hanabi_hip.ops import ActorMFMA
+
+        hidden = self.params.layers[0]
+        kp = (self.obs_len + 63) // 64 * 64
+        pa = self._plain_actor
+        if pa is None:
+            pa = self._plain_actor = ActorMFMA(self.obs_len, hidden, self.n_actions, 2, kp, self.device)   # (only its hidden half is used)
+            pa.stale = True
+        if pa.stale or self._eff_cache is None:
+            w1, w2 = self.online.weights[0].detach(), self.online.weights[1].detach()
+            b1, b2 = self.online.biases[0].detach(), self.online.biases[1].detach()
+            w1p = torch.zeros(kp, hidden, dtype=torch.bfloat16, device=self.device)
+            w1p[:self.obs_len] = w1.to(torch.bfloat16)
+            jobs = (K.HbPackJob * 1)()
+            j = jobs[0]
+            b1h = b1.to(torch.bfloat16).contiguous()
+            j.w, j.bias, j.wt, j.bias_out = w1p.data_ptr(), b1h.data_ptr(), pa.w1t.data_ptr(), pa.b1.data_ptr()
+            j.k_rows, j.n_cols, j.w_ld, j.group_cols, j.k_pad = self.obs_len, hidden, hidden, 0, kp
+            K.check(K.lib().hb_actor_pack_weights(jobs, 1, K.current_stream()))
+            pa.w2f, pa.b2f = w2.to(torch.bfloat16).float().contiguous(), b2.float().contiguous()
+            pa.stale = False
+            self._eff_cache = True
+        n = obs.shape[0]
+        if pa.h is None or pa.h.shape[0] != n:
+            pa.h = torch.empty(n, hidden, dtype=torch.bfloat16, device=self.device)
+        packed = obs.dtype == torch.int32
+        L, s = K.lib(), K.current_stream()
+        fn = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden
+        K.check(fn(K.dptr(obs.contiguous()), n, self.obs_len, K.dptr(pa.w1t), kp, K.dptr(pa.b1), hidden, K.dptr(pa.h), s))
+        q = torch.addmm(pa.b2f, pa.h.float(), pa.w2f)                      # [N, A] fp32: a tiny GEMM
+        actions = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._draws += 1
+        K.check(L.hb_policy_select(K.dptr(q), K.dptr(legal.to(torch.int8).contiguous()), n, self.n_actions, float(epsilon),
+                                   self.params.seed + 0x9E3779B9, self._draws, self.first_game_id, K.dptr(actions), s))
+        self._last_q = q
+        return actions
+
     def _act_fused(self, obs, legal, epsilon):
         """Actor on the GPU: int8 obs -> GEMM dtype, two bias-fused MFMA GEMMs, then ONE kernel for
         softmax-expectation + legal mask + epsilon-greedy sample (hb_policy_act)."""
@@ -275,8 +321,8 @@ class DQNAgent:
     @torch.no_grad()
     def exploit(self, observations):
         obs, legal, on_device = self._unpack(observations)
-        if self._fused:
-            actions = self._act_fused(obs, legal, 0.0)
+        if self._fused or self._plain_fast:
+            actions = (self._act_fused if self._fused else self._act_plain)(obs, legal, 0.0)
             return actions if on_device else actions.cpu().numpy()
         if self.params.resample_noise:
             self.online.resample()
@@ -287,8 +333,8 @@ class DQNAgent:
     @torch.no_grad()
     def explore(self, observations):
         obs, legal, on_device = self._unpack(observations)
-        if self._fused:
-            actions = self._act_fused(obs, legal, float(self.params.epsilon(self.train_step)))
+        if self._fused or self._plain_fast:
+            actions = (self._act_fused if self._fused else self._act_plain)(obs, legal, float(self.params.epsilon(self.train_step)))
             return actions if on_device else actions.cpu().numpy()
         if self.params.resample_noise:
             self.online.resample()

@@ -173,6 +173,60 @@ def test_full_size_properties_32768_games():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_full_size_properties_5_players_32768_games(packed):
+    """BASELINE config 4's per-GPU leg (5-player full Hanabi, 32 768 games, obs 1280, 48 moves, 192-byte state rows):
+    size-independent structure of the GPU output plus an oracle comparison on a 256-game slice, int8 and bit-packed output."""
+    import hanabi_hip
+    import torch
+
+    n, P = 32768, 5
+    flags = O.FLAG_AUTO_RESET | O.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", P, flags), n_games=n, seed=77, packed=packed)
+    assert (env.obs_len, env.num_actions, env.state_words, env.obs_words) == (1280, 48, 48, 40)
+    sl = slice(30000, 30256)
+    orc = O.OracleEnv(O.make_config("Hanabi-Full", P, flags), 256, seed=77, first_game_id=30000)
+    terminals = 0
+    for t in range(160):
+        act = env.random_legal_actions(seed=99, draw=t)
+        env.step(act)
+        out = orc.step(act[sl].cpu().numpy())
+        terminals += int(env.terminal.sum().item())
+        if t % 20 == 0 or t == 159:
+            obs = env.obs.cpu().numpy()
+            assert set(np.unique(obs)) <= {0, 1}
+            assert np.array_equal(obs[sl], out["obs"]) and np.array_equal(env.legal[sl].cpu().numpy(), out["legal"])
+            assert np.array_equal(env.agent_reward[sl].cpu().numpy(), out["agent_reward"])
+            assert np.array_equal(env.agent_step_type[sl].cpu().numpy(), out["agent_step_type"])
+            st = env.export_state().cpu().numpy().view(np.uint32)
+            assert np.array_equal(st[sl], orc.export_state())
+            # sections (App. A.6, 5 players): hands 400 | flags 5 | deck 30 | fireworks 25 | info 8 | life 3 | discards 50 | last 59 | knowledge 700
+            hands = obs[:, 0:400].reshape(n, 16, 25)
+            assert (hands.sum(2) <= 1).all()
+            deck = obs[:, 405:435]
+            assert (np.diff(deck.astype(np.int8), axis=1) <= 0).all() and (deck.sum(1) == (st[:, 0] & 63)).all()
+            fw = obs[:, 435:460].reshape(n, 5, 5)
+            assert (fw.sum(2) <= 1).all()
+            assert (obs[:, 460:468].sum(1) == ((st[:, 0] >> 6) & 15)).all() and (obs[:, 468:471].sum(1) == ((st[:, 0] >> 10) & 7)).all()
+            assert (((st[:, 0] >> 13) & 7) == (t + 1) % P).all()                       # lock-step seat
+            last = obs[:, 521:580]
+            assert (last[:, 0:5].sum(1) <= 1).all() and (last[:, 5:9].sum(1) == last[:, 0:5].sum(1)).all()   # actor and type together
+            kn = obs[:, 580:1280].reshape(n, 20, 35)
+            assert (kn[:, :, 25:30].sum(2) <= 1).all() and (kn[:, :, 30:35].sum(2) <= 1).all()
+            # a hand that is short shows its flag, its empty card slot and an empty knowledge slot
+            hn = np.stack([(st[:, 1] >> (15 + 3 * p)) & 7 for p in range(P)], axis=1)
+            cur = (st[:, 0] >> 13) & 7
+            for rel in range(P):
+                short = hn[np.arange(n), (cur + rel) % P] < 4
+                assert np.array_equal(obs[:, 400 + rel] == 1, short)
+            assert (legal_rows := env.legal.cpu().numpy()).sum(1).min() >= 1 and legal_rows.shape == (n, 48)
+            if packed:
+                from hanabi_agents.rlax_dqn import bitpack
+
+                assert torch.equal(bitpack.unpack(env.obs_bits, 1280), env.obs)
+    assert terminals > n // 2 and env.illegal_count() == 0
+
+
 def test_unaligned_output_is_rejected():
     import ctypes as C
 

@@ -522,3 +522,89 @@ def test_adam_shared_moments_equal_separate_moments():
             outs.append(p + [m_w, v_w, m_mu, v_mu, m_s, v_s, eff])
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+def test_vanilla_double_dqn_gpu_equals_cpu_reference():
+    """BASELINE config 2 (scalar double-DQN, uniform replay; spec hanabi_agents/rlax_dqn/rlax_dqn.py:170-205): the GPU agent's
+    loss, per-sample TD errors, gradient and weights after an update equal the torch-CPU fp32 evaluation of the same
+    arithmetic on the same weights and batch (the hand KAT of tests/test_learner.py pins that arithmetic itself)."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, DQNLearning, ObservationSpec, RlaxRainbowParams
+
+    n, obs_len, n_act = 256, 658, 20
+    params = RlaxRainbowParams(distributional=False, use_priority=False, train_batch_size=n, experience_buffer_size=n,
+                               target_update_period=2, seed=11)
+    gpu = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False)
+    cpu = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cpu")
+    rng = np.random.default_rng(0)
+    o1, o2 = (rng.integers(0, 2, (n, obs_len)).astype(np.int8) for _ in range(2))
+    legal = np.ones((n, n_act), np.int8)
+    act, rew = rng.integers(0, n_act, n), rng.integers(-1, 3, n).astype(np.float32)
+    st = rng.integers(1, 3, n)
+    for a in (gpu, cpu):
+        with torch.no_grad():
+            for b in a.online.biases:
+                b.fill_(0.05)
+            for p, q in zip(a.target.parameters(), a.online.parameters()):
+                p.copy_(q * 0.9)
+        a.add_experience_first((None, (o1, legal)), np.zeros(n))
+        a.add_experience((None, (o2, legal)), act, rew, st)
+        a.experience.sample_indices_dev = lambda b, a=a: torch.arange(b, device=a.device)
+    # loss / td / gradient of the first update
+    outs = []
+    for a in (gpu, cpu):
+        tr = a.experience.gather_dev(torch.arange(n, device=a.device))
+        tr = tr._replace(observation_tm1=tr.observation_tm1.float(), observation_t=tr.observation_t.float())
+        loss, td = DQNLearning.loss(a.online, a.target, a.atoms, tr, 0.99, torch.ones(n, dtype=torch.float64, device=a.device), 0.4,
+                                    distributional=False)
+        g = torch.autograd.grad(loss, list(a.online.parameters()))
+        outs.append((loss.detach().cpu(), td.cpu(), torch.cat([x.reshape(-1) for x in g]).cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-6 + 1e-4 * float(outs[1][2].abs().max()))
+    terminal = st == 2   # the older agent zeroes the bootstrap at terminal states (rlax_dqn.py:178)
+    assert terminal.any() and float(outs[1][1].max()) > 0
+    for _ in range(3):
+        gpu.update()
+        cpu.update()
+    for p, q in zip(gpu.online.parameters(), cpu.online.parameters()):
+        assert torch.allclose(p.cpu(), q, rtol=1e-3, atol=2e-5)
+    for p, q in zip(gpu.target.parameters(), cpu.target.parameters()):
+        assert torch.allclose(p.cpu(), q, rtol=1e-3, atol=2e-5)
+
+
+def test_vanilla_fast_actor_matches_torch_policy():
+    """bf16 vanilla agent on the GPU: hidden layer on the MFMA kernel (int8 and bit-packed observations), output layer on the
+    library GEMM, hb_policy_select — against DQNPolicy.q_values in fp32: q within the bf16 tolerance, arg-max wherever the
+    top-2 gap is clear, identical actions for the two observation forms."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, DQNPolicy, ObservationSpec, RlaxRainbowParams, bitpack
+    from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
+
+    n, obs_len, n_act = 1000, 658, 20
+    params = RlaxRainbowParams(distributional=False, use_priority=False, experience_buffer_size=1024, compute_dtype="bfloat16",
+                               epsilon=0.0)
+    agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda")
+    assert agent._plain_fast
+    g = torch.Generator(device="cuda").manual_seed(4)
+    obs = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.3).to(torch.int8)
+    legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.6).to(torch.int8)
+    legal[:, 1] = 1
+    with torch.no_grad():
+        agent.online.biases[0].normal_(0, 0.1, generator=g)
+        agent.online.biases[1].normal_(0, 0.1, generator=g)
+    agent._draws = 5
+    a8 = agent.exploit((None, (obs, legal))).clone()
+    q_fast = agent._last_q.clone()
+    agent._draws = 5
+    ab = agent.exploit((None, (bitpack.pack(obs), legal)))
+    assert torch.equal(a8, ab)
+    net32 = lambda x: torch.relu(x @ agent.online.weights[0] + agent.online.biases[0]) @ agent.online.weights[1] + agent.online.biases[1]
+    q32 = net32(obs.float())
+    assert float((q_fast - q32).abs().max()) < 0.05 * float(q32.abs().max()) + TOLERANCE["bfloat16"]["q_abs"]
+    masked = torch.where(legal.bool(), q32, torch.full_like(q32, float("-inf")))
+    top2 = masked.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05
+    assert clear.float().mean() > 0.3 and torch.equal(a8[clear].long(), masked.argmax(1)[clear])
+    assert bool(legal.gather(1, a8.long()[:, None]).all())
