@@ -74,6 +74,7 @@ def _parse():
                     help="reserve this many CUs for the learner stream (CU-masked streams); 0 = no partition")
     ap.add_argument("--no-learner-stream", action="store_true", help="run the updates in order on the main stream")
     ap.add_argument("--learner-priority", type=int, default=-1, help="HIP stream priority of the learner stream (-1 = high)")
+    ap.add_argument("--stream-per-agent", type=int, default=-1, help="1: one learner stream per agent, 0: one shared, -1: default")
     ap.add_argument("--unpacked-obs", action="store_true",
                     help="int8 [N, obs_len] observations end to end (the reference's layout) instead of the bit-packed rows")
     ap.add_argument("--launch-check", action="store_true",
@@ -327,7 +328,8 @@ def main():
             lstream = masked_stream(0, args.learner_cus, device)
             main_stream = masked_stream(args.learner_cus, 256, device)
         session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_stream=lstream,
-                                  learner_priority=args.learner_priority)
+                                  learner_priority=args.learner_priority,
+                                  stream_per_agent=None if args.stream_per_agent < 0 else bool(args.stream_per_agent))
 
     act = torch.empty(n, dtype=torch.int32, device=device)
     draw = [0]

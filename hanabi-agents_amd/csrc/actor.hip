@@ -30,6 +30,7 @@
 #include <hip/hip_bf16.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/hanabi_hip.h"
 #include "common.hpp"
@@ -311,6 +312,185 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the same GEMM (same tile, same fragment reads, same MFMA order: bit-identical results), built so that the
+// learner's kernels can run BESIDE it on the same CUs (the self-play loop overlaps one seat's update with the other seat's
+// policy forward; with 232 VGPRs x 2 waves per SIMD and 133 KB of LDS the first form leaves room for nothing else, and a
+// learner kernel queued behind 256-512 of its workgroups waits 30-50 us for a CU):
+//   * weights (and, for the output layer, the hidden activations) go global -> LDS directly (global_load_lds, 16 B per
+//     lane, XOR swizzle applied on the SOURCE address): no staging registers, no ds_write pass;
+//   * bit-packed observations: a thread fetches ONE dword (32 observation bits of one row) per K step, two steps ahead, and
+//     expands it into the next stage's activation tile while the current step multiplies;
+//   * the epilogue reuses the main loop's 128 KB of LDS, half a tile at a time.
+typedef const __attribute__((address_space(1))) void* hb_gptr_t;
+typedef __attribute__((address_space(3))) void* hb_lptr_t;
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((hb_gptr_t)g, (hb_lptr_t)l, 16, 0, 0);  // LDS address: wave-uniform base + lane * 16
+}
+constexpr int LDS2_BYTES = 2 * STAGE;  // 131 072
+
+template <int MODE>  // 1: output layer + C51 expectation (x = bf16 hidden activations); 2: hidden layer from bit-packed observations
+__global__ __launch_bounds__(NT) void actor_gemm2_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS2_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int rt = static_cast<int>(blockIdx.x), ct = static_cast<int>(blockIdx.y);
+  if ((gridDim.x & 7u) == 0) {  // XCD-aware tile order (see actor_gemm_kernel)
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, label = lin & 7u, slot = lin >> 3;
+    ct = static_cast<int>(slot % gridDim.y);
+    rt = static_cast<int>((slot / gridDim.y) * 8u + label);
+  }
+  const long long row0 = static_cast<long long>(rt) * BM;
+  const int col0 = ct * BN;
+  const int kt_n = a.k_pad / BK;
+
+  // ---- direct-to-LDS staging: one wave instruction writes 1 KiB = 8 rows x 128 B; lane l owns (row l >> 3, physical chunk
+  // l & 7) and fetches the LOGICAL chunk that the swizzled read expects there
+  const int lr = lane >> 3, pc = lane & 7;
+  const unsigned char* wsrc[4];
+  const unsigned char* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 32 * wave + 8 * i + lr;
+    const int c = pc ^ ((r >> 1) & 7);
+    wsrc[i] = reinterpret_cast<const unsigned char*>(a.wt + static_cast<long long>(col0 + r) * a.k_pad) + c * 16;
+    if (MODE == 1) {
+      long long row = row0 + r;
+      if (row >= a.m) row = a.m - 1;
+      xsrc[i] = reinterpret_cast<const unsigned char*>(static_cast<const __hip_bfloat16*>(a.x) + row * a.x_ld) + c * 16;
+    }
+  }
+  auto stage = [&](int kt, unsigned char* base) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned char* dst = base + (32 * wave + 8 * i) * ROWB;
+      if (MODE == 1) glds16(xsrc[i] + kt * (BK * 2), dst);
+      glds16(wsrc[i] + kt * (BK * 2), dst + BM * ROWB);
+    }
+  };
+  // ---- bit-packed observations: thread -> (row tid >> 1, half tid & 1): the 32 bits k = 64 kt + 32 half .. + 31 of its row
+  const int br = tid >> 1, bh = tid & 1;
+  const uint32_t* bsrc = nullptr;
+  if (MODE == 2) {
+    long long row = row0 + br;
+    if (row >= a.m) row = a.m - 1;
+    bsrc = reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(a.x) + row * a.x_ld) + bh;
+  }
+  const int n_words = a.k_real >> 5;  // MODE 2: words per row
+  auto load_bits = [&](int kt) -> uint32_t { return (2 * kt + bh < n_words) ? bsrc[2 * kt] : 0u; };
+  auto expand_bits = [&](uint32_t b, unsigned char* base) {
+    unsigned char* rowp = base + br * ROWB;
+    const int sw = (br >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t v = b >> (8 * j);
+      *reinterpret_cast<uint4*>(rowp + (((4 * bh + j) ^ sw) << 4)) =
+          make_uint4(bits2_bf16(v, 0), bits2_bf16(v, 1), bits2_bf16(v, 2), bits2_bf16(v, 3));
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = BM * ROWB + (wc * 64 + (lane & 15)) * ROWB;
+
+  uint32_t bits_next = 0;
+  if (MODE == 2) {
+    expand_bits(load_bits(0), lds);
+    if (kt_n > 1) bits_next = load_bits(1);
+  }
+  stage(0, lds);
+  for (int kt = 0; kt < kt_n; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage kt complete for every wave (LDS-DMA landed, expansions written); the other stage is free
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    unsigned char* nxt = lds + ((kt + 1) & 1) * STAGE;
+    uint32_t bits_after = 0;
+    if (MODE == 2 && kt + 2 < kt_n) bits_after = load_bits(kt + 2);   // (issued BEFORE the LDS-DMAs: an older load)
+    if (kt + 1 < kt_n) stage(kt + 1, nxt);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = ((kk * 4 + fq) ^ fsw) << 4;
+      bf16x8 wf[4], xf[8];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+      if (MODE == 2 && kk == 0 && kt + 1 < kt_n) expand_bits(bits_next, nxt);  // VALU + 4 LDS writes beside the MFMAs
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[n][m], 0, 0, 0);
+    }
+    bits_next = bits_after;
+  }
+  __syncthreads();
+
+  // ---- epilogue, 128 rows at a time through the (now idle) staging LDS: pass p takes the wavefronts with wr == p
+  for (int p = 0; p < 2; ++p) {
+    if (wr == p) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int cl = wc * 64 + n * 16 + fq * 4;
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + col0 + cl);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          float v0 = acc[n][m][0] + b.x, v1 = acc[n][m][1] + b.y, v2 = acc[n][m][2] + b.z, v3 = acc[n][m][3] + b.w;
+          if (MODE != 1) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          const int rl = m * 16 + (lane & 15);
+          *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+        }
+      }
+    }
+    __syncthreads();
+    const long long rbase = row0 + p * 128;
+    if (MODE != 1) {
+#pragma unroll 4
+      for (int i = 0; i < 8; ++i) {  // coalesced copy-out: 32 chunks of 16 bytes per row
+        const int id = tid + NT * i, r = id >> 5, ch = id & 31;
+        if (rbase + r < a.m)
+          *reinterpret_cast<uint4*>(a.h + (rbase + r) * a.h_ld + col0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + r * OUT_LD + ch * 16);
+      }
+    } else {
+      const int K = a.n_atoms;
+      const int first_action = ct * a.group_actions;
+      int ga = a.n_actions - first_action;
+      if (ga > a.group_actions) ga = a.group_actions;
+      for (int id = tid; id < 128 * ga; id += NT) {
+        const int r = id & 127, al = id >> 7;
+        float qv;
+        if (K == 51) {  // `al` is wave-uniform
+          const int start = al * 51 * 2, lead = (start & 7) >> 1;
+          const uint2* p8 = reinterpret_cast<const uint2*>(lds + r * OUT_LD + (start & ~7));
+          if (lead == 0) qv = c51_expectation<51, 0>(p8, a.support);
+          else if (lead == 1) qv = c51_expectation<51, 1>(p8, a.support);
+          else if (lead == 2) qv = c51_expectation<51, 2>(p8, a.support);
+          else qv = c51_expectation<51, 3>(p8, a.support);
+        } else {
+          const uint16_t* pp = reinterpret_cast<const uint16_t*>(lds + r * OUT_LD) + al * K;
+          float mx = -INFINITY;
+          for (int k = 0; k < K; ++k) mx = fmaxf(mx, __uint_as_float(static_cast<uint32_t>(pp[k]) << 16));
+          float s = 0.f, t = 0.f;
+          for (int k = 0; k < K; ++k) {
+            const float e = __expf(__uint_as_float(static_cast<uint32_t>(pp[k]) << 16) - mx);
+            s += e;
+            t += e * a.support[k];
+          }
+          qv = t / s / static_cast<float>(K);
+        }
+        if (rbase + r < a.m) a.q[(rbase + r) * a.n_actions + first_action + al] = qv;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // weights [K][N] (row stride w_ld) -> transposed [n'][k_pad] with n' = (n / group_cols) * 256 + n % group_cols
 // (group_cols = 0: n' = n); bias -> fp32 at the same n'. 32 x 32 tiles through LDS; up to 4 matrices per launch
 // (workgroup b belongs to job j where first[j] <= b < first[j + 1]). Rows / columns that no input maps to are left
@@ -408,6 +588,12 @@ __global__ __launch_bounds__(SEL_T) void policy_select_kernel(const float* __res
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// The first (register-staged) GEMM form is the default: measured 28.6 / 40.1 us (hidden / q at 32 768 rows) against 31.6 / 41.9 us
+// for the direct-to-LDS form, which HB_ACTOR_FORM=2 selects for A/B measurements; results are bit-identical
+bool use_first_form() {
+  static const int v = [] { const char* e = getenv("HB_ACTOR_FORM"); return e && e[0] == '2' ? 0 : 1; }();
+  return v != 0;
+}
 }  // namespace
 
 extern "C" {
@@ -464,7 +650,8 @@ int hb_actor_hidden_packed(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t
   a.wt = static_cast<const __hip_bfloat16*>(w1t_dev); a.bias = b1_dev;
   a.h = static_cast<__hip_bfloat16*>(h_dev); a.h_ld = hidden;
   const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(hidden / BN));
-  hipLaunchKernelGGL((actor_gemm_kernel<2>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  if (use_first_form()) hipLaunchKernelGGL((actor_gemm_kernel<2>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL((actor_gemm2_kernel<2>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }
@@ -483,7 +670,8 @@ int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2
   a.group_actions = 256 / n_atoms;
   const int groups = (n_actions + a.group_actions - 1) / a.group_actions;
   const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(groups));
-  hipLaunchKernelGGL((actor_gemm_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  if (use_first_form()) hipLaunchKernelGGL((actor_gemm_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL((actor_gemm2_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

@@ -75,6 +75,26 @@ __device__ __forceinline__ void wave_fence() {
 
 constexpr int DL_LD = 64;  // row stride of the compact gradient (K <= 64 atoms, zero padded)
 
+// eight 16-bit floats <-> one 16-byte vector, through registers only (no local arrays that end up in scratch)
+template <typename T> __device__ __forceinline__ float half_lo(uint32_t d);
+template <typename T> __device__ __forceinline__ float half_hi(uint32_t d);
+template <> __device__ __forceinline__ float half_lo<__hip_bfloat16>(uint32_t d) { return __uint_as_float(d << 16); }
+template <> __device__ __forceinline__ float half_hi<__hip_bfloat16>(uint32_t d) { return __uint_as_float(d & 0xFFFF0000u); }
+template <> __device__ __forceinline__ float half_lo<__half>(uint32_t d) { return __low2float(*reinterpret_cast<const __half2*>(&d)); }
+template <> __device__ __forceinline__ float half_hi<__half>(uint32_t d) { return __high2float(*reinterpret_cast<const __half2*>(&d)); }
+template <> __device__ __forceinline__ float half_lo<float>(uint32_t d) { return __uint_as_float(d); }
+template <> __device__ __forceinline__ float half_hi<float>(uint32_t d) { return 0.f; }
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<__hip_bfloat16>(float lo, float hi) {
+  const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+  return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+}
+template <> __device__ __forceinline__ uint32_t pack2<__half>(float lo, float hi) {
+  const __half2 h = __floats2half2_rn(lo, hi);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+template <> __device__ __forceinline__ uint32_t pack2<float>(float lo, float) { return __float_as_uint(lo); }
+
 // one logits row (+ its bias) -> LDS as fp32, 16 elements per lane at a time: all 16 (32 with the bias) loads of a round are
 // issued before the first LDS write, so they share one memory round trip
 template <typename T>
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
     constexpr bool VEC_IO = JT * sizeof(T) == 16;
     const bool vec = VEC_IO && j0 + JT <= a.H && ((a.h_ld | a.H) & (JT - 1)) == 0;
     float dlv[CPP][VEC];
-    T hin[JT];
+    float hin[JT];   // this sample's JT hidden activations (only their sign is used)
     int c0 = 0;
     auto load_sample = [&](int base) {
       const int b = base + (tid >> 2);
@@ -260,10 +280,16 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
       }
       c0 = a.act[bb] * SLOT;
       if (vec) {
-        *reinterpret_cast<uint4*>(hin) = *reinterpret_cast<const uint4*>(h + static_cast<long long>(bb) * a.h_ld + j0);
+        const uint4 u = *reinterpret_cast<const uint4*>(h + static_cast<long long>(bb) * a.h_ld + j0);
+        const uint32_t d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < JT / 2; ++i) {
+          hin[2 * i] = half_lo<T>(d[i & 3]);
+          hin[2 * i + 1] = half_hi<T>(d[i & 3]);
+        }
       } else {
 #pragma unroll
-        for (int jj = 0; jj < JT; ++jj) hin[jj] = j0 + jj < a.H ? h[static_cast<long long>(bb) * a.h_ld + j0 + jj] : static_cast<T>(0.f);
+        for (int jj = 0; jj < JT; ++jj) hin[jj] = j0 + jj < a.H ? ld<T>(h, static_cast<long long>(bb) * a.h_ld + j0 + jj) : 0.f;
       }
     };
     load_sample(0);
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
       const int b = base + (tid >> 2);
       const bool live = b < a.B;
       if (base > 0) load_sample(base);
-      T gout[JT];
+      float gout[JT];
 #pragma unroll
       for (int jj = 0; jj < JT; ++jj) {
         const uint4* wr = reinterpret_cast<const uint4*>(w2s + jj * ld_w + c0);
@@ -323,17 +349,20 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
         }
         acc += dpp_mov<0xb1, 0xf>(acc, acc);      // parts (0,1) and (2,3)
         acc += dpp_mov<0x4e, 0xf>(acc, acc);      // ... and the two pairs: every lane of the quad holds the dot product
-        const float g = ld<T>(hin, jj) > 0.f ? acc : 0.f;
-        st<T>(gout, jj, g);
+        const float g = hin[jj] > 0.f ? acc : 0.f;
+        gout[jj] = g;
         if (live && part == 0 && j0 + jj < a.H) colsum[jj] += rounded<T>(g);   // the column sum of dH as it is stored
       }
       if (live && part == 0) {
         if (vec) {
-          *reinterpret_cast<uint4*>(dh + static_cast<long long>(b) * a.H + j0) = *reinterpret_cast<const uint4*>(gout);
+          uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int i = 0; i < JT / 2; ++i) d[i & 3] = pack2<T>(gout[2 * i], gout[2 * i + 1]);
+          *reinterpret_cast<uint4*>(dh + static_cast<long long>(b) * a.H + j0) = make_uint4(d[0], d[1], d[2], d[3]);
         } else {
 #pragma unroll
           for (int jj = 0; jj < JT; ++jj)
-            if (j0 + jj < a.H) dh[static_cast<long long>(b) * a.H + j0 + jj] = gout[jj];
+            if (j0 + jj < a.H) st<T>(dh, static_cast<long long>(b) * a.H + j0 + jj, gout[jj]);
         }
       }
     }

@@ -24,7 +24,7 @@ from . import _capi as K
 
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
-                 learner_stream=True, learner_priority=-1):
+                 learner_stream=True, learner_priority=-1, stream_per_agent=None):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -51,6 +51,9 @@ class SelfPlaySession:
         import torch.distributed as dist
 
         self._dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # one learner stream per agent: seat A's update (launched at step t, needed at t + P) runs beside seat B's (t + 1):
+        # the two latency-bound kernel chains interleave instead of queueing one behind the other
+        self._stream_per_agent = self._dp if stream_per_agent is None else bool(stream_per_agent)
         self._lstreams = {}
         self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
         self.env_steps = 0
@@ -109,7 +112,7 @@ class SelfPlaySession:
         """One learner stream with a single rank (measured best: 0.195 ms per step). Data-parallel: one per agent, so that
         seat A's gradient all-reduce (tens of microseconds of xGMI latency in the middle of its update) is in flight while
         seat B's update computes, instead of both queueing on one stream whose updates would then outlast a step."""
-        if not self._dp:
+        if not self._stream_per_agent:
             return self.learner_stream
         ls = self._lstreams.get(id(agent))
         if ls is None:
