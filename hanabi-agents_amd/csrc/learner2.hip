@@ -282,10 +282,15 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
       if (vec) {
         const uint4 u = *reinterpret_cast<const uint4*>(h + static_cast<long long>(bb) * a.h_ld + j0);
         const uint32_t d[4] = {u.x, u.y, u.z, u.w};
+        if constexpr (sizeof(T) == 4) {            // JT = 4 floats
 #pragma unroll
-        for (int i = 0; i < JT / 2; ++i) {
-          hin[2 * i] = half_lo<T>(d[i & 3]);
-          hin[2 * i + 1] = half_hi<T>(d[i & 3]);
+          for (int i = 0; i < JT; ++i) hin[i] = __uint_as_float(d[i & 3]);
+        } else {                                   // JT = 8 sixteen-bit values
+#pragma unroll
+          for (int i = 0; i < JT / 2; ++i) {
+            hin[2 * i] = half_lo<T>(d[i & 3]);
+            hin[2 * i + 1] = half_hi<T>(d[i & 3]);
+          }
         }
       } else {
 #pragma unroll
@@ -356,8 +361,13 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
       if (live && part == 0) {
         if (vec) {
           uint32_t d[4] = {0u, 0u, 0u, 0u};
+          if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int i = 0; i < JT / 2; ++i) d[i & 3] = pack2<T>(gout[2 * i], gout[2 * i + 1]);
+            for (int i = 0; i < JT; ++i) d[i & 3] = __float_as_uint(gout[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < JT / 2; ++i) d[i & 3] = pack2<T>(gout[2 * i], gout[2 * i + 1]);
+          }
           *reinterpret_cast<uint4*>(dh + static_cast<long long>(b) * a.H + j0) = make_uint4(d[0], d[1], d[2], d[3]);
         } else {
 #pragma unroll

@@ -26,6 +26,8 @@
 //                  (strict <, subtract-on-right: sum_tree.h:92-105) are replayed from registers
 //                  with v_readlane, so cap = 2^19 costs 4 dependent loads instead of 19.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include <cstdlib>
 #include <new>
@@ -46,6 +48,7 @@ struct hb_tree {
   float* scratch;     // large per_update: transformed priorities
   long long scratch_n;
   bool single_wg;     // measurements only (env HB_TREE_UPDATE_PATH=single at creation): force update_small
+  bool lazy_top;      // hb_tree_set_lazy_top: writers leave the levels above the 1024-leaf subtrees stale, readers re-sum them
 };
 
 namespace {
@@ -319,8 +322,10 @@ __global__ void per_transform_kernel(const float* __restrict__ td, float* __rest
 // ---------------------------------------------------------------------------------------------
 // sample: one wavefront per query
 // ---------------------------------------------------------------------------------------------
+// `top` (optional): an LDS copy of nodes [0, top_n) — the levels above the 1024-leaf subtrees, re-summed by the caller when
+// the tree keeps them lazily (hb_tree_set_lazy_top); nodes at or beyond top_n are read from memory
 __device__ __forceinline__ long long wave_descend(const float* __restrict__ nodes, long long cap, int depth, float query,
-                                                  int lane, float* leaf_val) {
+                                                  int lane, float* leaf_val, const float* top = nullptr, int top_n = 0) {
   long long node = 1;
   int remaining = depth;
   while (remaining > 0) {
@@ -331,7 +336,7 @@ __device__ __forceinline__ long long wave_descend(const float* __restrict__ node
     if (lane >= 1 && lane < (1 << k)) {
       const int d = 31 - __clz(lane);
       const long long parent = (node << d) + (lane - (1 << d));
-      left = nodes[2 * parent];
+      left = 2 * parent < top_n ? top[2 * parent] : nodes[2 * parent];
     }
     int t = 1;  // wave-uniform: kept in SGPRs so the broadcast is a v_readlane, not a ds_bpermute
     for (int s = 0; s < k; ++s) {
@@ -398,6 +403,99 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// per_sample (uniforms drawn in the kernel) + the replay gather of learner.hip in ONE launch: workgroup i descends the tree for
+// stratum i with its first wavefront, then all four wavefronts expand the two observation rows of the sampled transition
+// (obs_tm1 -> x[i], obs_t of the n-step chain's last transition -> x[B + i]) into the GEMM operand. Same arithmetic as
+// per_sample_kernel (unit == 2) followed by gather_kernel; saves a launch and a dependent kernel boundary on the learner's
+// critical path.
+struct SampleGatherArgs {
+  const float* nodes; long long cap; int depth;
+  unsigned long long seed; const float* counter; int batch;
+  int64_t* idx; double* prob;
+  const void* ring_tm1; const void* ring_t; const int8_t* ring_act; const float* ring_rew; const uint8_t* ring_term;
+  int L, packed_words; void* x; int x_dtype, x_ld;
+  int32_t* act; float* rew; float* term; float* disc;
+  const long long* size_wp; long long ring_cap, n_ins; int n_step; float gamma;
+  int ntop;   // > 0: the tree keeps its top levels lazily; every workgroup re-sums them from the ntop subtree roots in LDS
+};
+template <typename T> __device__ __forceinline__ void sg_store(T* p, long long i, float v);
+template <> __device__ __forceinline__ void sg_store<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void sg_store<__hip_bfloat16>(__hip_bfloat16* p, long long i, float v) { p[i] = __float2bfloat16(v); }
+template <> __device__ __forceinline__ void sg_store<__half>(__half* p, long long i, float v) { p[i] = __float2half(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void per_sample_gather_kernel(const SampleGatherArgs a) {
+  __shared__ long long s_slot[2];
+  extern __shared__ float s_top[];  // 2 * ntop floats in lazy-top mode
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long i = blockIdx.x;
+  const int B = a.batch;
+  if (a.ntop > 0) {
+    // the same pairwise sums rebuild_top_kernel would have stored (every inner node = fl(left + right)): identical bits
+    for (int j = threadIdx.x; j < a.ntop; j += 256) s_top[a.ntop + j] = a.nodes[a.ntop + j];
+    __syncthreads();
+    for (int w = a.ntop >> 1; w >= 1; w >>= 1) {
+      for (int j = threadIdx.x; j < w; j += 256) s_top[w + j] = s_top[2 * (w + j)] + s_top[2 * (w + j) + 1];
+      __syncthreads();
+    }
+  }
+  if (wave == 0) {
+    const double start = 1.0 / static_cast<double>(B);
+    const double step = B > 1 ? (1.0 - start) / static_cast<double>(B - 1) : 0.0;
+    const double lin = (B > 1 && i == B - 1) ? 1.0 : static_cast<double>(i) * step + start;
+    const float total = a.ntop > 0 ? s_top[1] : a.nodes[1];
+    const unsigned long long c = static_cast<unsigned long long>(*a.counter);
+    uint32_t r[4];
+    hb::philox4x32_10(static_cast<uint32_t>(i), static_cast<uint32_t>(static_cast<unsigned long long>(i) >> 32),
+                      static_cast<uint32_t>(c), static_cast<uint32_t>(c >> 32), static_cast<uint32_t>(a.seed),
+                      static_cast<uint32_t>(a.seed >> 32), r);
+    const unsigned long long bits = (static_cast<unsigned long long>(r[0] >> 5) << 26) | (r[1] >> 6);
+    const double ui = static_cast<double>(bits) * 0x1.0p-53 / static_cast<double>(B);
+    const float query = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(static_cast<float>(lin - ui) * total)));
+    float leaf;
+    const long long k = wave_descend(a.nodes, a.cap, a.depth, query, lane, &leaf, s_top, 2 * a.ntop);
+    if (lane == 0) {
+      a.idx[i] = k;
+      a.prob[i] = (static_cast<double>(leaf) + 1e-10) / static_cast<double>(total);
+      // the n-step chain of this sample (gather_kernel, learner.hip): a handful of dependent 1-byte / 4-byte reads
+      long long j = k;
+      float R = a.ring_rew[j], g = a.gamma;
+      int m = 1;
+      if (a.n_step > 1) {
+        const long long size = a.size_wp[0], wp = a.size_wp[1];
+        const long long ahead = size >= a.ring_cap ? ((wp - 1 - k) % a.ring_cap + a.ring_cap) % a.ring_cap : size - 1 - k;
+        while (m < a.n_step && !a.ring_term[j] && static_cast<long long>(m) * a.n_ins <= ahead) {
+          j = (j + a.n_ins) % a.ring_cap;
+          R += g * a.ring_rew[j];
+          g *= a.gamma;
+          ++m;
+        }
+      }
+      a.rew[i] = R;
+      a.term[i] = a.ring_term[j] ? 1.f : 0.f;
+      a.disc[i] = g;
+      a.act[i] = a.ring_act[k];
+      s_slot[0] = k;
+      s_slot[1] = j;
+    }
+  }
+  __syncthreads();
+  T* x = static_cast<T*>(a.x);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const long long slot = s_slot[half];
+    T* dst = x + (static_cast<long long>(half) * B + i) * a.x_ld;
+    if (a.packed_words > 0) {
+      const uint32_t* src = static_cast<const uint32_t*>(half == 0 ? a.ring_tm1 : a.ring_t) + slot * a.packed_words;
+      for (int jj = threadIdx.x; jj < a.L; jj += 256) sg_store<T>(dst, jj, static_cast<float>((src[jj >> 5] >> (jj & 31)) & 1u));
+    } else {
+      const int8_t* src = static_cast<const int8_t*>(half == 0 ? a.ring_tm1 : a.ring_t) + slot * a.L;
+      for (int jj = threadIdx.x; jj < a.L; jj += 256) sg_store<T>(dst, jj, static_cast<float>(src[jj]));
+    }
+  }
+}
+
 __global__ void get_kernel(const float* __restrict__ nodes, long long cap, const int64_t* __restrict__ idx,
                            float* __restrict__ val, long long n, unsigned long long* errors) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -409,6 +507,17 @@ __global__ void get_kernel(const float* __restrict__ nodes, long long cap, const
   } else {
     val[i] = nodes[cap + k];
   }
+}
+
+void launch_top(hb_tree* t, hipStream_t s) {
+  const int ntop = static_cast<int>(t->cap / t->chunk);
+  if (ntop > 1)
+    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
+                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+}
+// lazy mode: the levels above the subtree roots are only as fresh as the last reader made them
+void freshen_top(hb_tree* t, hipStream_t s) {
+  if (t->lazy_top) launch_top(t, s);
 }
 
 int rebuild(hb_tree* t, int first_chunk, int nchunks_touched, hipStream_t s) {
@@ -443,6 +552,7 @@ int hb_tree_create(int64_t capacity, hb_tree** out) {
   t->stamp = nullptr;
   t->scratch = nullptr;
   t->scratch_n = 0;
+  t->lazy_top = false;
   {
     const char* path = getenv("HB_TREE_UPDATE_PATH");
     t->single_wg = path && path[0] == 's';
@@ -476,9 +586,7 @@ static int update_impl(hb_tree* t, const int64_t* idx, const float* val, int64_t
   if (n >= 96 && n <= SMALL_MAX && t->cap >= 4 * static_cast<long long>(t->chunk) && !t->single_wg) {
     hipLaunchKernelGGL(update_chunks_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
                        idx, val, static_cast<int>(n), per_mode, alpha, max_prio, min_prio, t->errors);
-    const int ntop = static_cast<int>(t->cap / t->chunk);
-    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
-                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+    if (!t->lazy_top) launch_top(t, s);
     HB_HIP(hipGetLastError());
     return HB_OK;
   }
@@ -539,10 +647,7 @@ int hb_tree_fill_range(hb_tree* t, int64_t start, int64_t n, const float* value_
   hipLaunchKernelGGL((chunk_kernel<true>), dim3(static_cast<unsigned>(touched)), dim3(256), 0, s, t->nodes, t->cap,
                      t->chunk, static_cast<int>(start / t->chunk), static_cast<long long>(start),
                      static_cast<long long>(n), value_dev);
-  const int ntop = static_cast<int>(nchunks);
-  if (ntop > 1)
-    hipLaunchKernelGGL(rebuild_top_kernel, dim3(1), dim3(ntop >= 2048 ? 1024 : (ntop / 2 < 64 ? 64 : ntop / 2)),
-                       2 * ntop * sizeof(float), s, t->nodes, ntop);
+  if (!t->lazy_top) launch_top(t, s);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }
@@ -551,6 +656,7 @@ int hb_tree_sample(hb_tree* t, const float* quantile_dev, int64_t* idx_dev, floa
   if (!t) return fail(HB_ERR_INVALID, "null tree");
   if (n <= 0) return HB_OK;
   if (!quantile_dev || !idx_dev) return fail(HB_ERR_INVALID, "null argument");
+  freshen_top(t, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(sample_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, quantile_dev, idx_dev, val_dev,
                      static_cast<long long>(n));
@@ -563,6 +669,7 @@ int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_u
   if (!t) return fail(HB_ERR_INVALID, "null tree");
   if (batch <= 0) return HB_OK;
   if (!u_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
+  freshen_top(t, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, u_dev, static_cast<long long>(batch),
                      unit_uniforms != 0 ? 1 : 0, 0ull, static_cast<const float*>(nullptr), idx_dev, prob_dev);
@@ -575,9 +682,42 @@ int hb_per_sample_philox(hb_tree* t, uint64_t seed, const float* counter_dev, in
   if (!t) return fail(HB_ERR_INVALID, "null tree");
   if (batch <= 0) return HB_OK;
   if (!counter_dev || !idx_dev || !prob_dev) return fail(HB_ERR_INVALID, "null argument");
+  freshen_top(t, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(per_sample_kernel, dim3(static_cast<unsigned>((batch + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t->nodes, t->cap, t->depth, static_cast<const double*>(nullptr),
                      static_cast<long long>(batch), 2, static_cast<unsigned long long>(seed), counter_dev, idx_dev, prob_dev);
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_per_sample_gather(hb_tree* t, uint64_t seed, const float* counter_dev, int64_t batch, int64_t* idx_dev, double* prob_dev,
+                         const void* ring_obs_tm1_dev, const void* ring_obs_t_dev, const int8_t* ring_act_dev,
+                         const float* ring_rew_dev, const uint8_t* ring_term_dev, int32_t obs_len, int32_t packed, void* x_dev,
+                         int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev, float* term_dev, float* disc_dev,
+                         int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert, const int64_t* size_wp_dev,
+                         void* stream) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (batch <= 0) return HB_OK;
+  if (!counter_dev || !idx_dev || !prob_dev || !ring_obs_tm1_dev || !ring_obs_t_dev || !ring_act_dev || !ring_rew_dev ||
+      !ring_term_dev || !x_dev || !act_dev || !rew_dev || !term_dev || !disc_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (obs_len < 1 || x_ld < obs_len) return fail(HB_ERR_INVALID, "x_ld must be >= obs_len >= 1");
+  if (n_step < 1) return fail(HB_ERR_INVALID, "n_step must be >= 1");
+  if (n_step > 1 && (!size_wp_dev || rows_per_insert < 1 || capacity < 1))
+    return fail(HB_ERR_INVALID, "n_step > 1 needs size_wp_dev, rows_per_insert and capacity");
+  SampleGatherArgs a{t->nodes, t->cap, t->depth, static_cast<unsigned long long>(seed), counter_dev, static_cast<int>(batch),
+                     idx_dev, prob_dev, ring_obs_tm1_dev, ring_obs_t_dev, ring_act_dev, ring_rew_dev, ring_term_dev, obs_len,
+                     packed ? (obs_len + 31) / 32 : 0, x_dev, x_dtype, x_ld, act_dev, rew_dev, term_dev, disc_dev,
+                     reinterpret_cast<const long long*>(size_wp_dev), capacity, rows_per_insert, n_step, gamma, 0};
+  const int ntop = static_cast<int>(t->cap / t->chunk);
+  if (t->lazy_top && ntop > 1) a.ntop = ntop;
+  const size_t lds = static_cast<size_t>(2 * a.ntop) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(batch)), block(256);
+  if (x_dtype == 0) hipLaunchKernelGGL((per_sample_gather_kernel<float>), grid, block, lds, s, a);
+  else if (x_dtype == 1) hipLaunchKernelGGL((per_sample_gather_kernel<__hip_bfloat16>), grid, block, lds, s, a);
+  else if (x_dtype == 2) hipLaunchKernelGGL((per_sample_gather_kernel<__half>), grid, block, lds, s, a);
+  else return fail(HB_ERR_INVALID, "x_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   HB_HIP(hipGetLastError());
   return HB_OK;
 }
@@ -595,12 +735,21 @@ int hb_tree_get(hb_tree* t, const int64_t* idx_dev, float* val_dev, int64_t n, v
 
 int hb_tree_total(hb_tree* t, float* total_dev, void* stream) {
   if (!t || !total_dev) return fail(HB_ERR_INVALID, "null argument");
+  freshen_top(t, static_cast<hipStream_t>(stream));
   HB_HIP(hipMemcpyAsync(total_dev, t->nodes + 1, sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+
+int hb_tree_set_lazy_top(hb_tree* t, int32_t on) {
+  if (!t) return fail(HB_ERR_INVALID, "null tree");
+  if (t->lazy_top && !on) launch_top(t, nullptr);   // leaving lazy mode: make the stored top levels valid again
+  t->lazy_top = on != 0;
   return HB_OK;
 }
 
 int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream) {
   if (!t || !nodes_dev) return fail(HB_ERR_INVALID, "null argument");
+  freshen_top(t, static_cast<hipStream_t>(stream));
   HB_HIP(hipMemcpyAsync(nodes_dev, t->nodes, 2 * t->cap * sizeof(float), hipMemcpyDeviceToDevice,
                         static_cast<hipStream_t>(stream)));
   return HB_OK;

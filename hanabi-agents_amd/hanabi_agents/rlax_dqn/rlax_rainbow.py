@@ -514,6 +514,9 @@ class DQNAgent:
             from .fused_learner import FusedLearner
 
             self._fl = FusedLearner(self)
+            if self.params.use_priority:
+                # the fused sample + gather launch re-sums the tree's top levels itself: writers can skip that launch
+                self.experience.sum_tree.set_lazy_top(True)
         return self._fl
 
     def _sample_indices(self):
@@ -538,9 +541,15 @@ class DQNAgent:
                 self.target.resample()
                 fl.refresh_effective()
                 fl.refresh_target()
-            indices, prios = self._sample_indices()
+            if self.params.use_priority and "_sample_indices" not in self.__dict__:
+                # PER: tree descent and replay gather in one launch (same draws as _sample_indices below)
+                indices, prios = fl.sample_and_gather(self.params.seed + 0x51ED270B + 0x9E3779B1 * self.first_game_id)
+                gathered = True
+            else:
+                indices, prios = self._sample_indices()
+                gathered = False
             self._note_local_is_max(prios)
-            td, _ = fl.part1(indices, prios)
+            td, _ = fl.part1(indices, prios, gathered=gathered)
             return None, indices, td  # the loss value is formed on demand (last_loss) from td and the IS weights
         indices, prios, tr = self._sample()
         self._note_local_is_max(prios)

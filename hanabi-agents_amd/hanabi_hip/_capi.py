@@ -109,6 +109,7 @@ SIGNATURES = {
     "hb_tree_nodes": (_P, [_P]),
     "hb_tree_export_nodes": (C.c_int, [_P, _P, _P]),
     "hb_tree_import_nodes": (C.c_int, [_P, _P, _P]),
+    "hb_tree_set_lazy_top": (C.c_int, [_P, _I32]),
     "hb_tree_update": (C.c_int, [_P, _P, _P, _I64, _P]),
     "hb_tree_fill_range": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "hb_tree_sample": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
@@ -117,6 +118,8 @@ SIGNATURES = {
     "hb_tree_error_count": (C.c_int, [_P, C.POINTER(_I64)]),
     "hb_per_sample": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "hb_per_sample_philox": (C.c_int, [_P, _U64, _P, _I64, _P, _P, _P]),
+    "hb_per_sample_gather": (C.c_int, [_P, _U64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32,
+                                       C.c_float, _I64, _I64, _P, _P]),
     "hb_per_update": (C.c_int, [_P, _P, _P, _I64, _F64, _P, _P, _P]),
     "hb_obs_cast": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "hb_policy_act": (C.c_int, [_P, _I32, _P, _P, _I64, _I32, _I32, _I32, C.c_float, _U64, _U64, _I64, _P, _P, _P]),

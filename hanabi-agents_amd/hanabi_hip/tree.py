@@ -83,6 +83,10 @@ class SumTree:
         K.check(self.L.hb_per_update(self.h, K.dptr(idx), K.dptr(td), idx.numel(), float(alpha), K.dptr(max_prio_dev),
                                      K.dptr(min_prio_dev), K.current_stream()))
 
+    def set_lazy_top(self, on=True):
+        """Writers stop re-summing the levels above the 1024-leaf subtrees; readers do it (hb_tree_set_lazy_top)."""
+        K.check(self.L.hb_tree_set_lazy_top(self.h, 1 if on else 0))
+
     def nodes(self):
         """Copy of the 2*capacity heap (root at index 1) as a CUDA tensor (tests)."""
         out = torch.empty(2 * self.capacity, dtype=torch.float32, device=self.device)

@@ -245,6 +245,13 @@ int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream);
  * nodes keep the exact fp32 values the incremental updates had produced)                          */
 int hb_tree_import_nodes(hb_tree* t, const float* nodes_dev, void* stream);
 
+/* Lazy top levels. Writers (hb_tree_update / hb_per_update with 96..1024 entries, hb_tree_fill_range) rebuild the 1024-leaf
+ * subtrees they touch and then re-sum the levels above them in a second, one-workgroup launch. on != 0 drops that launch:
+ * the levels above the subtree roots go stale and every READER makes them fresh first — hb_per_sample_gather inside its own
+ * workgroups (in LDS, the same pairwise sums: identical bits), the other readers (hb_tree_sample, hb_per_sample[_philox],
+ * hb_tree_total, hb_tree_export_nodes) by running the re-sum launch themselves. Results never depend on the mode.          */
+int hb_tree_set_lazy_top(hb_tree* t, int32_t on);
+
 /* update_values(indices, values) (sum_tree.h:38-44). Duplicate indices inside one call:
  * the LAST occurrence wins (the sequential order of the reference loop). n<=0 is a no-op.
  * Out-of-range indices are ignored and counted in hb_tree_error_count().                */
@@ -283,6 +290,15 @@ int hb_per_sample(hb_tree* t, const double* u_dev, int64_t batch, int32_t unit_u
  * learner passes its optimizer step count).                                                         */
 int hb_per_sample_philox(hb_tree* t, uint64_t seed, const float* counter_dev, int64_t batch, int64_t* idx_dev,
                          double* prob_dev, void* stream);
+/* hb_per_sample_philox and hb_replay_gather(_packed) (below) in ONE launch: workgroup i descends the tree for stratum i, then
+ * expands the sampled transition's two observation rows into x_dev. Outputs and arithmetic are exactly those of the two
+ * separate calls; `packed` != 0: the rings hold bit-packed rows (hb_replay_gather_packed), else int8 rows.              */
+int hb_per_sample_gather(hb_tree* t, uint64_t seed, const float* counter_dev, int64_t batch, int64_t* idx_dev, double* prob_dev,
+                         const void* ring_obs_tm1_dev, const void* ring_obs_t_dev, const int8_t* ring_act_dev,
+                         const float* ring_rew_dev, const uint8_t* ring_term_dev, int32_t obs_len, int32_t packed, void* x_dev,
+                         int32_t x_dtype, int32_t x_ld, int32_t* act_dev, float* rew_dev, float* term_dev, float* disc_dev,
+                         int32_t n_step, float gamma, int64_t capacity, int64_t rows_per_insert, const int64_t* size_wp_dev,
+                         void* stream);
 /* hb_per_update: p_i = (|td_i| + 1e-10)^alpha (double pow, rounded to float as the
  * pybind float conversion does), max/min priority tracked in device scalars
  * (priority_buffer.py:48-52), then hb_tree_update.                                      */

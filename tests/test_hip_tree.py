@@ -229,3 +229,94 @@ def test_per_sample_philox_draws_match_host_philox():
     a, _ = t.per_sample_philox_dev(seed, torch.tensor(1.0, device="cuda"), batch)
     b, _ = t.per_sample_philox_dev(seed, torch.tensor(2.0, device="cuda"), batch)
     assert not torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed,n_step", [(False, 1), (True, 1), (True, 3)])
+def test_fused_sample_gather_equals_the_two_separate_launches(packed, n_step):
+    """hb_per_sample_gather == hb_per_sample_philox followed by hb_replay_gather(_packed): same indices, probabilities and
+    GEMM operand, bit for bit."""
+    import torch
+
+    from hanabi_agents.rlax_dqn.priority_buffer import PriorityBuffer
+    from hanabi_hip import _capi as K
+
+    L, A, n, cap, B = 658, 20, 64, 64 * 6, 128
+    g = torch.Generator(device="cuda").manual_seed(7 + n_step)
+    buf = PriorityBuffer(L, A, 1, cap, device="cuda", packed=packed)
+    buf.track_wp = True
+    for k in range(8):
+        o1, o2 = ((torch.rand(n, L, device="cuda", generator=g) < 0.4).to(torch.int8) for _ in range(2))
+        buf.add_transitions(o1, torch.randint(0, A, (n, 1), device="cuda", generator=g), torch.randint(-1, 3, (n, 1), device="cuda", generator=g).float(),
+                            o2, torch.ones(n, A, dtype=torch.int8, device="cuda"), torch.rand(n, 1, device="cuda", generator=g) < 0.2)
+        buf.update_priorities_dev(torch.randint(0, cap, (50,), device="cuda", generator=g), torch.rand(50, device="cuda", generator=g))
+    buf.sync_size()
+    counter = torch.tensor(5.0, device="cuda")
+    lib, s = K.lib(), K.current_stream()
+    outs = []
+    for fused in (False, True):
+        idx = torch.empty(B, dtype=torch.int64, device="cuda")
+        prob = torch.empty(B, dtype=torch.float64, device="cuda")
+        x = torch.zeros(2 * B, 704, dtype=torch.bfloat16, device="cuda")
+        act = torch.empty(B, dtype=torch.int32, device="cuda")
+        rew, term, disc = (torch.empty(B, device="cuda") for _ in range(3))
+        if fused:
+            K.check(lib.hb_per_sample_gather(buf.sum_tree.h, 99, K.dptr(counter), B, K.dptr(idx), K.dptr(prob), K.dptr(buf._obs_tm1_buf),
+                                             K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf), K.dptr(buf._rew_t_buf),
+                                             K.dptr(buf._terminal_t_buf), L, 1 if packed else 0, K.dptr(x), 1, 704, K.dptr(act), K.dptr(rew),
+                                             K.dptr(term), K.dptr(disc), n_step, 0.99, cap, n, K.dptr(buf._size_wp), s))
+        else:
+            K.check(lib.hb_per_sample_philox(buf.sum_tree.h, 99, K.dptr(counter), B, K.dptr(idx), K.dptr(prob), s))
+            fn = lib.hb_replay_gather_packed if packed else lib.hb_replay_gather
+            K.check(fn(K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf), K.dptr(buf._rew_t_buf),
+                       K.dptr(buf._terminal_t_buf), K.dptr(idx), B, L, K.dptr(x), 1, 704, K.dptr(act), K.dptr(rew), K.dptr(term),
+                       K.dptr(disc), n_step, 0.99, cap, n, K.dptr(buf._size_wp), s))
+        outs.append((idx, prob, x, act, rew, term, disc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][2].any() and len(set(outs[0][0].tolist())) > B // 2
+
+
+@pytest.mark.gpu
+def test_lazy_top_levels_give_identical_results():
+    import torch
+
+    from hanabi_hip import _capi as K
+    import hanabi_hip
+
+    cap, B, L = 1 << 14, 128, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    trees = [hanabi_hip.SumTree(cap), hanabi_hip.SumTree(cap)]
+    trees[1].set_lazy_top(True)
+    mx, mn = [torch.tensor([0.6], device="cuda") for _ in trees], [torch.tensor([0.6], device="cuda") for _ in trees]
+    ring = torch.zeros(cap, L, dtype=torch.int8, device="cuda")
+    ring_act = torch.zeros(cap, 1, dtype=torch.int8, device="cuda")
+    ring_rew = torch.zeros(cap, 1, device="cuda")
+    ring_term = torch.zeros(cap, 1, dtype=torch.bool, device="cuda")
+    size_wp = torch.tensor([cap, 0], dtype=torch.int64, device="cuda")
+    counter = torch.tensor(1.0, device="cuda")
+    lib, s = K.lib(), K.current_stream()
+    for rnd in range(6):
+        idx = torch.randint(0, cap, (256,), device="cuda", generator=g)
+        td = torch.rand(256, device="cuda", generator=g)
+        start = int(torch.randint(0, cap, (1,), generator=torch.Generator().manual_seed(rnd)).item())
+        outs = []
+        for t, a, b in zip(trees, mx, mn):
+            t.fill_range_dev(start, 3000, a)              # ring insert (wraps for late starts)
+            t.per_update_dev(idx, td, 0.6, a, b)          # 256 entries: the per-subtree path
+            i_out = torch.empty(B, dtype=torch.int64, device="cuda")
+            p_out = torch.empty(B, dtype=torch.float64, device="cuda")
+            x = torch.zeros(2 * B, L, device="cuda")
+            act = torch.empty(B, dtype=torch.int32, device="cuda")
+            rew, term, disc = (torch.empty(B, device="cuda") for _ in range(3))
+            K.check(lib.hb_per_sample_gather(t.h, 5, K.dptr(counter), B, K.dptr(i_out), K.dptr(p_out), K.dptr(ring), K.dptr(ring),
+                                             K.dptr(ring_act), K.dptr(ring_rew), K.dptr(ring_term), L, 0, K.dptr(x), 0, L, K.dptr(act),
+                                             K.dptr(rew), K.dptr(term), K.dptr(disc), 1, 0.99, cap, 1, K.dptr(size_wp), s))
+            outs.append((i_out, p_out))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), rnd
+        counter += 1
+    u = torch.rand(B, dtype=torch.float64, device="cuda", generator=g)
+    a, b = trees[0].per_sample_dev(u, unit=True), trees[1].per_sample_dev(u, unit=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert trees[0].get_total_val() == trees[1].get_total_val()
+    assert torch.equal(trees[0].nodes(), trees[1].nodes())
