@@ -81,29 +81,26 @@ __global__ __launch_bounds__(NT) void gemm_v0(const Args a) {
   const int col0 = static_cast<int>(blockIdx.y) * BN;
   const int kt_n = a.k / BK;
   const int sc = tid & 7, sr = tid >> 3;
-  uint4 xr[4], wq[4];
+  uint4 xr0, xr1, xr2, xr3, wq0, wq1, wq2, wq3;
   STAMP(0);
-  auto load_stage = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = sr + 64 * i;
-      long long row = row0 + r;
-      if (row >= a.m) row = a.m - 1;
-      const int k = kt * BK + sc * 8;
-      xr[i] = *reinterpret_cast<const uint4*>(a.x + row * a.k + k);
-      wq[i] = *reinterpret_cast<const uint4*>(a.wt + static_cast<long long>(col0 + r) * a.k + k);
-    }
-  };
-  auto store_stage = [&](int buf) {
-    unsigned char* base = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = sr + 64 * i;
-      const int off = r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(base + off) = xr[i];
-      *reinterpret_cast<uint4*>(base + OPB + off) = wq[i];
-    }
-  };
+#define P_LOAD_ONE(i, XR, WQ)                                                                   \
+  {                                                                                             \
+    const int r = sr + 64 * (i);                                                                \
+    long long row = row0 + r;                                                                   \
+    if (row >= a.m) row = a.m - 1;                                                              \
+    const int k = kt_ * BK + sc * 8;                                                            \
+    XR = *reinterpret_cast<const uint4*>(a.x + row * a.k + k);                                  \
+    WQ = *reinterpret_cast<const uint4*>(a.wt + static_cast<long long>(col0 + r) * a.k + k);    \
+  }
+#define P_LOAD_STAGE(KT) { const int kt_ = (KT); P_LOAD_ONE(0, xr0, wq0) P_LOAD_ONE(1, xr1, wq1) P_LOAD_ONE(2, xr2, wq2) P_LOAD_ONE(3, xr3, wq3) }
+#define P_STORE_ONE(i, XR, WQ)                                              \
+  {                                                                         \
+    const int r = sr + 64 * (i);                                            \
+    const int off = r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4);                \
+    *reinterpret_cast<uint4*>(base_ + off) = XR;                            \
+    *reinterpret_cast<uint4*>(base_ + OPB + off) = WQ;                      \
+  }
+#define P_STORE_STAGE(BUF) { unsigned char* base_ = lds + (BUF) * STAGE; P_STORE_ONE(0, xr0, wq0) P_STORE_ONE(1, xr1, wq1) P_STORE_ONE(2, xr2, wq2) P_STORE_ONE(3, xr3, wq3) }
   f32x4 acc[4][8];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -112,16 +109,16 @@ __global__ __launch_bounds__(NT) void gemm_v0(const Args a) {
   const int fsw = (lane & 15) >> 1, fq = lane >> 4;
   const int x_off = (wr * 128 + (lane & 15)) * ROWB;
   const int w_off = OPB + (wc * 64 + (lane & 15)) * ROWB;
-  load_stage(0);
-  store_stage(0);
-  if (kt_n > 1) load_stage(1);
+  P_LOAD_STAGE(0)
+  P_STORE_STAGE(0)
+  if (kt_n > 1) P_LOAD_STAGE(1)
   __syncthreads();
   STAMP(1);
   for (int kt = 0; kt < kt_n; ++kt) {
     const unsigned char* cur = lds + (kt & 1) * STAGE;
-    if (kt + 1 < kt_n) store_stage((kt + 1) & 1);
+    if (kt + 1 < kt_n) P_STORE_STAGE((kt + 1) & 1)
     STAMP(2 + 4 * kt);
-    if (kt + 2 < kt_n) load_stage(kt + 2);
+    if (kt + 2 < kt_n) P_LOAD_STAGE(kt + 2)
     STAMP(3 + 4 * kt);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -286,6 +283,317 @@ __global__ __launch_bounds__(NT) void gemm_v3(const Args a) {
   STAMP(63);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// variant 4: register staging (loads two tiles ahead, as variant 0) + two wave groups half an iteration apart: group 0
+// (waves 0-3, rows 0-127) stores / loads in the first half of an iteration and multiplies in the second; group 1 (waves 4-7,
+// rows 128-255, the SIMD partners of group 0) multiplies the PREVIOUS tile in the first half and stores / loads in the second.
+// One barrier after each half. LDS: W in a ring of 3 tiles (96 KB: a tile is read by group 0 one half after it is complete
+// and by group 1 another half later), X per group double-buffered (4 x 16 KB): 160 KB.
+constexpr int W_TILE = BN * ROWB;            // 32 KB
+constexpr int XH_TILE = 128 * ROWB;          // 16 KB: one group's 128 rows
+constexpr int LDS4_BYTES = 3 * W_TILE + 4 * XH_TILE;   // 163 840
+template <bool STAMPS>
+__global__ __launch_bounds__(NT) void gemm_v4(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS4_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k / BK;
+  const int t = tid & 255, sc = t & 7, srl = t >> 3;   // within the group: chunk, row 0..31 (+ 32 i)
+  uint4 xr0, xr1, xr2, xr3, wq0, wq1, wq2, wq3;
+  STAMP(0);
+#define Q_LOAD_ONE(i, XR, WQ)                                                                                  \
+  {                                                                                                            \
+    const int r = wr * 128 + srl + 32 * (i);                                                                   \
+    long long row = row0 + r;                                                                                  \
+    if (row >= a.m) row = a.m - 1;                                                                             \
+    const int k = kt_ * BK + sc * 8;                                                                           \
+    XR = *reinterpret_cast<const uint4*>(a.x + row * a.k + k);                                                 \
+    WQ = *reinterpret_cast<const uint4*>(a.wt + static_cast<long long>(col0 + r) * a.k + k);                   \
+  }
+#define Q_LOAD_STAGE(KT) { const int kt_ = (KT); Q_LOAD_ONE(0, xr0, wq0) Q_LOAD_ONE(1, xr1, wq1) Q_LOAD_ONE(2, xr2, wq2) Q_LOAD_ONE(3, xr3, wq3) }
+#define Q_STORE_ONE(i, XR, WQ)                                                                  \
+  {                                                                                             \
+    const int rl = srl + 32 * (i);               /* row within the group's 128 */                \
+    const int r = wr * 128 + rl;                 /* row within the W tile */                      \
+    *reinterpret_cast<uint4*>(xb_ + rl * ROWB + ((sc ^ ((rl >> 1) & 7)) << 4)) = XR;            \
+    *reinterpret_cast<uint4*>(wb_ + r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4)) = WQ;              \
+  }
+#define Q_STORE_STAGE(KT)                                                                       \
+  {                                                                                             \
+    unsigned char* wb_ = lds + ((KT) % 3) * W_TILE;                                             \
+    unsigned char* xb_ = lds + 3 * W_TILE + (wr * 2 + ((KT) & 1)) * XH_TILE;                     \
+    Q_STORE_ONE(0, xr0, wq0) Q_STORE_ONE(1, xr1, wq1) Q_STORE_ONE(2, xr2, wq2) Q_STORE_ONE(3, xr3, wq3) \
+  }
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (lane & 15) * ROWB;                       // within the group's X buffer
+  const int w_off = (wc * 64 + (lane & 15)) * ROWB;           // within a W tile
+#define Q_MFMA(KT)                                                                                                   \
+  {                                                                                                                  \
+    const unsigned char* wcur = lds + ((KT) % 3) * W_TILE;                                                           \
+    const unsigned char* xcur = lds + 3 * W_TILE + (wr * 2 + ((KT) & 1)) * XH_TILE;                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                               \
+      const int ch = ((kk * 4 + fq) ^ fsw) << 4;                                                                     \
+      bf16x8 wf[4], xf[8];                                                                                           \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(wcur + w_off + n * 16 * ROWB + ch); \
+      _Pragma("unroll") for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xcur + x_off + m * 16 * ROWB + ch); \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                  \
+        _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                                \
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[n][m], 0, 0, 0);                     \
+    }                                                                                                                \
+  }
+  Q_LOAD_STAGE(0)
+  Q_STORE_STAGE(0)
+  if (kt_n > 1) Q_LOAD_STAGE(1)
+  __syncthreads();
+  STAMP(1);
+  for (int kt = 0; kt < kt_n; ++kt) {
+    // ---- first half: group 0 stores tile kt + 1 and loads tile kt + 2; group 1 multiplies tile kt - 1
+    if (wr == 0) {
+      if (kt + 1 < kt_n) Q_STORE_STAGE(kt + 1)
+      if (kt + 2 < kt_n) Q_LOAD_STAGE(kt + 2)
+    } else if (kt > 0) {
+      Q_MFMA(kt - 1)
+    }
+    STAMP(2 + 4 * kt);
+    __syncthreads();
+    STAMP(3 + 4 * kt);
+    // ---- second half: group 0 multiplies tile kt; group 1 stores tile kt + 1 and loads tile kt + 2
+    if (wr == 0) {
+      Q_MFMA(kt)
+    } else {
+      if (kt + 1 < kt_n) Q_STORE_STAGE(kt + 1)
+      if (kt + 2 < kt_n) Q_LOAD_STAGE(kt + 2)
+    }
+    STAMP(4 + 4 * kt);
+    __syncthreads();
+    STAMP(5 + 4 * kt);
+  }
+  if (wr == 1) Q_MFMA(kt_n - 1)
+  __syncthreads();
+  write_out(a, lds, acc, tid, row0, col0);
+  STAMP(63);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// variant 5: variant 0's data movement, but INSIDE the MFMA stream: the 8 LDS writes of the staged tile are interleaved with
+// the first K-half's 32 MFMAs and the 8 global loads of the tile after next with the second half's (sched_group_barrier), so
+// that the wave never sits in a store-only or load-issue-only phase while its SIMD's matrix pipe idles. Steady-state
+// iterations are branch-free (the last two are peeled).
+template <bool STAMPS>
+__global__ __launch_bounds__(NT) void gemm_v5(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k / BK;
+  const int sc = tid & 7, sr = tid >> 3;
+  uint4 xr0, xr1, xr2, xr3, wq0, wq1, wq2, wq3;
+  STAMP(0);
+  // per-thread source pointers (rows clamped once)
+  const __hip_bfloat16* xp[4];
+  const __hip_bfloat16* wp[4];
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = sr + 64 * i;
+    long long row = row0 + r;
+    if (row >= a.m) row = a.m - 1;
+    xp[i] = a.x + row * a.k + sc * 8;
+    wp[i] = a.wt + static_cast<long long>(col0 + r) * a.k + sc * 8;
+    soff[i] = r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4);
+  }
+#define R_LOAD(KT)                                                                                  \
+  {                                                                                                 \
+    const int ko = (KT) * BK;                                                                       \
+    xr0 = *reinterpret_cast<const uint4*>(xp[0] + ko); wq0 = *reinterpret_cast<const uint4*>(wp[0] + ko); \
+    xr1 = *reinterpret_cast<const uint4*>(xp[1] + ko); wq1 = *reinterpret_cast<const uint4*>(wp[1] + ko); \
+    xr2 = *reinterpret_cast<const uint4*>(xp[2] + ko); wq2 = *reinterpret_cast<const uint4*>(wp[2] + ko); \
+    xr3 = *reinterpret_cast<const uint4*>(xp[3] + ko); wq3 = *reinterpret_cast<const uint4*>(wp[3] + ko); \
+  }
+#define R_STORE(BUF)                                                                                \
+  {                                                                                                 \
+    unsigned char* base_ = lds + (BUF) * STAGE;                                                     \
+    *reinterpret_cast<uint4*>(base_ + soff[0]) = xr0; *reinterpret_cast<uint4*>(base_ + OPB + soff[0]) = wq0; \
+    *reinterpret_cast<uint4*>(base_ + soff[1]) = xr1; *reinterpret_cast<uint4*>(base_ + OPB + soff[1]) = wq1; \
+    *reinterpret_cast<uint4*>(base_ + soff[2]) = xr2; *reinterpret_cast<uint4*>(base_ + OPB + soff[2]) = wq2; \
+    *reinterpret_cast<uint4*>(base_ + soff[3]) = xr3; *reinterpret_cast<uint4*>(base_ + OPB + soff[3]) = wq3; \
+  }
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = OPB + (wc * 64 + (lane & 15)) * ROWB;
+#define R_FRAGS(KK)                                                                                                   \
+  const int ch##KK = ((KK * 4 + fq) ^ fsw) << 4;                                                                       \
+  bf16x8 wf##KK[4], xf##KK[8];                                                                                         \
+  _Pragma("unroll") for (int n = 0; n < 4; ++n) wf##KK[n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch##KK); \
+  _Pragma("unroll") for (int m = 0; m < 8; ++m) xf##KK[m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch##KK);
+#define R_MFMA(KK)                                                                                                     \
+  _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                        \
+    _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                                      \
+      acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf##KK[n], xf##KK[m], acc[n][m], 0, 0, 0);
+  R_LOAD(0)
+  R_STORE(0)
+  if (kt_n > 1) R_LOAD(1)
+  __syncthreads();
+  STAMP(1);
+  int kt = 0;
+  for (; kt + 2 < kt_n; ++kt) {   // steady state: store tile kt + 1, load tile kt + 2, multiply tile kt
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    {
+      R_FRAGS(0)
+      R_STORE((kt + 1) & 1)
+      R_MFMA(0)
+      // 12 fragment reads first, then 4 MFMAs per LDS write
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+    {
+      R_FRAGS(1)
+      R_LOAD(kt + 2)
+      R_MFMA(1)
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __syncthreads();
+  }
+  for (; kt < kt_n; ++kt) {       // the last two tiles: nothing left to load
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    if (kt + 1 < kt_n) R_STORE((kt + 1) & 1)
+    { R_FRAGS(0) R_MFMA(0) }
+    { R_FRAGS(1) R_MFMA(1) }
+    __syncthreads();
+  }
+  write_out(a, lds, acc, tid, row0, col0);
+  STAMP(63);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// variant 6: variant 5's schedule with the activations given as BITS (a.x = uint32 [M, k / 32], bit j of word w = element
+// 32 w + j, values 0 / 1): a thread fetches one dword per K step (two steps ahead) and expands it into four 16-byte LDS writes;
+// the weights go through registers as before. 5 global loads and 8 LDS writes per thread and step, all inside the MFMA stream.
+__device__ __forceinline__ uint32_t bits2_bf16(uint32_t b, int p) {
+  const uint32_t t = (b >> (2 * p)) & 3u;
+  return __umul24((t | (t << 15)) & 0x00010001u, 0x3F80u);
+}
+template <bool STAMPS>
+__global__ __launch_bounds__(NT) void gemm_v6(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k / BK;
+  const int sc = tid & 7, sr = tid >> 3;
+  uint4 wq0, wq1, wq2, wq3;
+  uint32_t bits_a, bits_b;   // the words of tiles kt + 1 and kt + 2
+  STAMP(0);
+  const __hip_bfloat16* wp[4];
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = sr + 64 * i;
+    wp[i] = a.wt + static_cast<long long>(col0 + r) * a.k + sc * 8;
+    soff[i] = r * ROWB + ((sc ^ ((r >> 1) & 7)) << 4);
+  }
+  const int br = tid >> 1, bh = tid & 1;
+  long long brow = row0 + br;
+  if (brow >= a.m) brow = a.m - 1;
+  const uint32_t* bp = reinterpret_cast<const uint32_t*>(a.x) + brow * (a.k / 32) + bh;
+  const int xoff = br * ROWB, xsw = (br >> 1) & 7;
+#define S_LOADW(KT)                                                                                 \
+  {                                                                                                 \
+    const int ko = (KT) * BK;                                                                       \
+    wq0 = *reinterpret_cast<const uint4*>(wp[0] + ko); wq1 = *reinterpret_cast<const uint4*>(wp[1] + ko); \
+    wq2 = *reinterpret_cast<const uint4*>(wp[2] + ko); wq3 = *reinterpret_cast<const uint4*>(wp[3] + ko); \
+  }
+#define S_STORE(BUF, BITS)                                                                          \
+  {                                                                                                 \
+    unsigned char* base_ = lds + (BUF) * STAGE;                                                     \
+    *reinterpret_cast<uint4*>(base_ + OPB + soff[0]) = wq0; *reinterpret_cast<uint4*>(base_ + OPB + soff[1]) = wq1; \
+    *reinterpret_cast<uint4*>(base_ + OPB + soff[2]) = wq2; *reinterpret_cast<uint4*>(base_ + OPB + soff[3]) = wq3; \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+      const uint32_t v_ = (BITS) >> (8 * j);                                                        \
+      *reinterpret_cast<uint4*>(base_ + xoff + (((4 * bh + j) ^ xsw) << 4)) =                       \
+          make_uint4(bits2_bf16(v_, 0), bits2_bf16(v_, 1), bits2_bf16(v_, 2), bits2_bf16(v_, 3));   \
+    }                                                                                               \
+  }
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = OPB + (wc * 64 + (lane & 15)) * ROWB;
+  bits_a = bp[0];
+  S_LOADW(0)
+  S_STORE(0, bits_a)
+  bits_a = kt_n > 1 ? bp[2] : 0u;
+  if (kt_n > 1) S_LOADW(1)
+  __syncthreads();
+  STAMP(1);
+  int kt = 0;
+  for (; kt + 2 < kt_n; ++kt) {   // steady state: store tile kt + 1 (W regs + bits_a), load tile kt + 2, multiply tile kt
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    {
+      R_FRAGS(0)
+      bits_b = bp[2 * (kt + 2)];
+      S_STORE((kt + 1) & 1, bits_a)
+      R_MFMA(0)
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // the expansion's VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+    {
+      R_FRAGS(1)
+      S_LOADW(kt + 2)
+      R_MFMA(1)
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    bits_a = bits_b;
+    __syncthreads();
+  }
+  for (; kt < kt_n; ++kt) {
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    if (kt + 1 < kt_n) S_STORE((kt + 1) & 1, bits_a)
+    { R_FRAGS(0) R_MFMA(0) }
+    { R_FRAGS(1) R_MFMA(1) }
+    __syncthreads();
+  }
+  write_out(a, lds, acc, tid, row0, col0);
+  STAMP(63);
+}
+
 }  // namespace
 
 extern "C" int probe_gemm(int variant, int stamped, const void* x, long long m, int k, const void* wt, int n, void* out,
@@ -302,6 +610,9 @@ extern "C" int probe_gemm(int variant, int stamped, const void* x, long long m, 
   if (variant == 0) LAUNCH(gemm_v0);
   else if (variant == 1) LAUNCH(gemm_v1);
   else if (variant == 3) LAUNCH(gemm_v3);
+  else if (variant == 4) LAUNCH(gemm_v4);
+  else if (variant == 5) LAUNCH(gemm_v5);
+  else if (variant == 6) LAUNCH(gemm_v6);
   else return -2;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
