@@ -338,6 +338,19 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
 /* ---- fused learner pieces (hanabi_agents/rlax_dqn/rlax_rainbow.py:152-217) ---------------
  * dtype codes: 0 = f32, 1 = bf16, 2 = f16.
  *
+ * Precision contract. dtype selects the type of the GEMM operands only (observations, effective weights, hidden
+ * activations, logits; the reference runs its whole network in f16, rlax_rainbow.py:250-251); master weights, Adam moments,
+ * softmax / projection / cross-entropy and every accumulation are f32. Against the f32 path on the same batch, weights and
+ * sampling probabilities (tests/test_dtype_parity.py asserts these on the MI355X; hanabi_agents/rlax_dqn/tolerance.py):
+ *                                                        bf16                      f16
+ *   per-sample td (where the double-Q selection is     |d| <= 0.01 + 0.004 |td|   |d| <= 0.002 + 0.0005 |td|
+ *     unambiguous in f32: top-2 gap > 4e-3 / 6e-4)
+ *   loss mean(td * w)                                   2e-3 relative              1e-4 relative
+ *   IS weights                                          1e-6 absolute              1e-6 absolute
+ *   merged gradients dW1, db1, dW2, db2 (rel. L2)       0.05                       0.03
+ *   actor q = mean_k softmax * atoms (|q| <= 0.49)      0.03 absolute              0.004 absolute
+ *   chosen move = f32 arg-max where the f32 top-2 gap   > 0.06                     > 0.008
+ *
  * hb_replay_gather: batch gather experience_buffer.py:83-87 straight into the GEMM operand:
  *   x_dev [2*batch, x_ld >= obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
  *   act_dev [B] int32, rew_dev [B] f32, term_dev [B] f32 (0/1), disc_dev [B] f32 = gamma^m.
