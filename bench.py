@@ -58,6 +58,10 @@ def _parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--prime", type=int, default=24,
+                    help="untimed SETUP steps before the W warm-up steps: the first updates capture the HIP graphs, pick the "
+                         "hipBLASLt algorithms and grow the allocator pools (one-time work, the counterpart of a compile "
+                         "step); reported as prime_steps")
     ap.add_argument("--games", type=int, default=None, help="games per GPU (default 32 768; 4 096 with --vanilla)")
     ap.add_argument("--vanilla", action="store_true",
                     help="BASELINE configs[1]: vanilla double-DQN (scalar Q head, rlax_dqn.py:170-205 spec) with uniform replay, "
@@ -65,7 +69,7 @@ def _parse():
     ap.add_argument("--players", type=int, default=2)
     ap.add_argument("--updates-per-step", type=int, default=1)
     ap.add_argument("--compute-dtype", default="bfloat16", choices=list(MFMA_PEAK_TFLOPS))
-    ap.add_argument("--games-per-wave", type=int, default=16)
+    ap.add_argument("--games-per-wave", type=int, default=None, help="8/16/32/64; default: the library's choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-games", type=int, default=4096)
     ap.add_argument("--cpu-sample-steps", type=int, default=150)
@@ -345,7 +349,7 @@ def main():
             draw[0] += 1
             env.step(act)
 
-    for _ in range(args.warmup):
+    for _ in range(args.prime + args.warmup):
         one_step()
     if session is not None:
         session.flush()
@@ -389,6 +393,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "prime_steps": args.prime,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",

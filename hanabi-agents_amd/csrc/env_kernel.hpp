@@ -297,13 +297,25 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
 
   // ---- phase 1: state rows HBM -> LDS (coalesced 16-byte loads) ---------------------------
   {
+    // every 16-byte piece of the wave's G rows is requested before the first one is written to LDS: ONE memory round trip
+    // for the whole copy (a run-time-bounded loop waits for each piece in turn: G / 8 round trips)
     constexpr int Q = K::SW / 4;
+    constexpr int ROUNDS = (G * Q + 63) / 64;
     const uint4* src = reinterpret_cast<const uint4*>(a.state + g0 * K::SW);
-    for (int e = lane; e < nvalid * Q; e += 64) {
-      const uint4 v = src[e];
-      const int g = e / Q, q = e - g * Q;
-      uint32_t* d = srow + g * K::SWP + 4 * q;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    uint4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int e = lane + 64 * r;
+      v[r] = e < nvalid * Q ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int e = lane + 64 * r;
+      if (e < nvalid * Q) {
+        const int g = e / Q, q = e - g * Q;
+        uint32_t* d = srow + g * K::SWP + 4 * q;
+        d[0] = v[r].x; d[1] = v[r].y; d[2] = v[r].z; d[3] = v[r].w;
+      }
     }
   }
   HB_STAMP(1);

@@ -208,7 +208,8 @@ int hb_rule_act(const hb_config* cfg, const uint32_t* state_rows_dev, int64_t n_
                 const hb_rule* rules, int32_t n_rules, uint64_t seed, uint64_t draw, int32_t* actions_dev,
                 int32_t* fired_dev, void* stream);
 
-/* Tuning knob for measurements: games handled per 64-lane wavefront (8, 16, 32 or 64).  */
+/* Tuning knob for measurements: games handled per 64-lane wavefront (8, 16, 32 or 64); 0 (the default) picks 16,
+ * or 32 for a packed-only step over >= 131072 games. The results do not depend on it.  */
 int hb_env_set_games_per_wave(hb_env* env, int32_t g);
 
 /* Deck-pool refill placement. Every game keeps its NEXT deck pre-shuffled in HBM, so a re-deal inside
