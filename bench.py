@@ -58,6 +58,10 @@ def _parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--actor-lag", type=int, default=0, choices=(0, 1),
+                    help="1: asynchronous actor (RlaxRainbowParams.actor_lag): double-buffered actor weights, the acting stream "
+                         "never waits for an update; 0 (default): the reference's synchronous semantics")
+    ap.add_argument("--no-async-variant", action="store_true", help="skip the second, asynchronous-actor measurement")
     ap.add_argument("--prime", type=int, default=24,
                     help="untimed SETUP steps before the W warm-up steps: the first updates capture the HIP graphs, pick the "
                          "hipBLASLt algorithms and grow the allocator pools (one-time work, the counterpart of a compile "
@@ -313,7 +317,8 @@ def main():
     session = None
     main_stream = None
     if not args.env_only:
-        params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=env.packed)
+        params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=env.packed,
+                                   actor_lag=args.actor_lag)
         if args.vanilla:
             params = params._replace(distributional=False, use_priority=False)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
@@ -409,6 +414,7 @@ def main():
                          + (f" x {world} GPUs (weak scaling: the same per GPU)" if world > 1 else "")),
             "games_per_gpu": n, "players": args.players, "train_batch": 256, "updates_per_step": args.updates_per_step,
             "policy": "random-legal (env only)" if args.env_only else "agent eps-greedy (eps 0.1)",
+            "actor_lag": args.actor_lag,
             "parallelism": f"dp{world}: games sharded, RCCL gradient all-reduce",
         },
         "grad_steps_per_sec": world * 0 + (grad_steps / dt if grad_steps else 0.0),
@@ -474,6 +480,9 @@ def main():
             if args.compute_dtype in TOLERANCE:
                 line["tolerance"] = dict(TOLERANCE[args.compute_dtype], dtype=args.compute_dtype, reference="fp32 PyTorch-autograd path "
                                          "(DQNLearning.loss + Adam; DQNPolicy.q_values)", test="tests/test_dtype_parity.py")
+    if (session is not None and not args.vanilla and args.actor_lag == 0 and args.compute_dtype == "bfloat16"
+            and not args.no_async_variant and env.packed):
+        line["async_actor"] = async_variant(args, rank, world, device, n)   # (every rank: it holds collectives)
     if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
         if not args.env_only:
@@ -484,6 +493,58 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def async_variant(args, rank, world, device, n):
+    """The same workload with the asynchronous actor (RlaxRainbowParams.actor_lag = 1, one learner stream per
+    agent), timed with the same protocol as the headline. Reported BESIDE the headline, which keeps the reference's
+    synchronous semantics: here the policy acts on weights that are one update old (tests/test_async_actor.py)."""
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", args.players, flags), n_games=n, seed=1234,
+                               first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device, packed=True)
+    params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=True, actor_lag=1)
+    agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s),
+                       device=device) for s in range(args.players)]
+    for a in agents:
+        a.first_game_id = rank * n
+    if world > 1:
+        for a in agents:
+            for t in list(a.online.parameters()) + list(a.online.buffers()):
+                dist.broadcast(t.data, 0)
+            a.target.load_state_dict(a.online.state_dict())
+    session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_priority=args.learner_priority,
+                              stream_per_agent=True)
+    for _ in range(args.prime + args.warmup):
+        session.step()
+    session.flush()
+    g0 = session.grad_steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        session.step()
+    session.flush()
+    host_s = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return {"actor_lag": 1, "learner_streams": "one per agent", "ms_per_step": dt / args.steps * 1e3,
+            "env_steps_per_sec": world * n * args.steps / dt, "grad_steps_per_sec": (session.grad_steps - g0) / dt,
+            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
+            "note": "policy acts on the weights of the update before last (one-update staleness, tests/test_async_actor.py); "
+                    "not the headline: the reference's agent is synchronous"}
 
 
 def qnet_roofline(agent, env, args):

@@ -464,4 +464,30 @@ int hb_random_legal_actions(const int8_t* legal_dev, int64_t n_games, int32_t n_
   return HB_OK;
 }
 
+
+// ---- stream ordering helpers for host drivers -------------------------------------------------------------------------
+// The self-play driver orders its acting and learner streams with events a few times per step; these wrappers cost
+// ~1 us from ctypes where the torch.cuda.Event methods cost ~8 us each (they look the current stream up first).
+int hb_event_create(void** event_out) {
+  if (!event_out) return fail(HB_ERR_INVALID, "null event_out");
+  hipEvent_t ev = nullptr;
+  HB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *event_out = ev;
+  return HB_OK;
+}
+int hb_event_destroy(void* event) {
+  if (event) HB_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return HB_OK;
+}
+int hb_event_record(void* event, void* stream) {
+  if (!event) return fail(HB_ERR_INVALID, "null event");
+  HB_HIP(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return HB_OK;
+}
+int hb_stream_wait_event(void* stream, void* event) {
+  if (!event) return fail(HB_ERR_INVALID, "null event");
+  HB_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+  return HB_OK;
+}
+
 }  // extern "C"

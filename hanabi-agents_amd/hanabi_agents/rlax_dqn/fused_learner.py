@@ -108,8 +108,19 @@ class FusedLearner:
 
         self.actor = None
         self.actor_stale = True
+        # params.actor_lag = 1: two actor weight sets. Update number u (counted from 0) packs its result into set u % 2 on the
+        # stream it ran on and records packed_ev[u % 2]; a policy call made when u updates have been launched reads set u % 2, i.e.
+        # the weights of update u - 2 (the initial weights while u < 2), which the update in flight (u - 1) does not touch.
+        self.lag = int(getattr(agent.params, "actor_lag", 0))
+        if self.lag not in (0, 1):
+            raise ValueError("actor_lag must be 0 or 1")
+        self.n_packed = 0
+        self.packed_ev = [None, None]
         if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd) and getattr(agent, "use_mfma_actor", True):
-            self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev)
+            self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev, n_sets=2 if self.lag else 1)
+        if self.lag and (self.actor is None or not agent.params.use_priority or agent.params.resample_noise):
+            raise ValueError("actor_lag=1 needs the MFMA actor (bf16 GEMM dtype, one hidden layer of a multiple of 256 units), "
+                             "prioritized replay and frozen noise")
         self._gw2_out = torch.zeros(H, self.Np, dtype=self.cd, device=dev)
         self._gw1_out = torch.zeros(self.Kp, H, dtype=self.cd, device=dev)
         self.refresh_effective()
@@ -130,11 +141,38 @@ class FusedLearner:
     def pack_actor(self):
         """Refresh the actor's transposed weight copies if the effective weights changed since the last call. Runs on
         the ACTING stream just before the actor kernels (the update that wrote `eff` has been waited for by then), so the
-        two small launches stay off the learner chain, which is the critical path of a step."""
+        two small launches stay off the learner chain, which is the critical path of a step. (actor_lag=1: only after the
+        weights were replaced wholesale — construction, restore, checkpoint load; updates pack through weights_updated().)"""
         if self.actor is not None and self.actor_stale:
             (w1, b1), (w2, b2) = self.eff
-            self.actor.pack(w1, b1, w2, b2)
+            for s in range(self.actor.n_sets):
+                self.actor.pack(w1, b1, w2, b2, s)
             self.actor_stale = False
+            self.packed_ev = [None, None]
+
+    def weights_updated(self):
+        """Called after every optimizer step, on the stream the step ran on."""
+        if not self.lag:
+            self.actor_stale = True   # repacked lazily before the next policy call
+            return
+        self.pack_actor()
+        s = self.n_packed % 2
+        (w1, b1), (w2, b2) = self.eff
+        self.actor.pack(w1, b1, w2, b2, s)
+        if self.packed_ev[s] is None:
+            self.packed_ev[s] = K.Event()
+        self.packed_ev[s].record()
+        self.n_packed += 1
+
+    def acting_set(self):
+        """The weight set the next policy call reads; the calling stream is made to wait for the launch that packed it."""
+        self.pack_actor()
+        if not self.lag:
+            return 0
+        s = self.n_packed % 2
+        if self.packed_ev[s] is not None:
+            self.packed_ev[s].wait()
+        return s
 
     @torch.no_grad()
     def refresh_target(self):

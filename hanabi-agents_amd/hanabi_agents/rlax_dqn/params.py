@@ -42,6 +42,10 @@ class RlaxRainbowParams(NamedTuple):
     global_is_max: bool = False              # data-parallel only: normalise the IS weights by the max over ALL ranks' batches (one
                                              #     extra 4-byte all-reduce(max) per update), i.e. exactly the reference's w /= max(w)
                                              #     over the global batch (rlax_rainbow.py:188-189); False: per-rank max
+    actor_lag: int = 0                       # 0: the actor always uses the newest weights (the reference; it waits for its own update).
+                                             # 1: asynchronous actor: double-buffered actor weights, the policy acts on
+                                             #     the weights of the update BEFORE the most recent one, so acting never waits for the
+                                             #     learner; the one-update staleness is the only difference (tests/test_async_actor.py)
 
 
 try:  # optional: same registration the reference performs (params.py:4)

@@ -195,6 +195,13 @@ class DQNAgent:
         self._draws = 0             # Philox draw counter of the fused sampler
         self.first_game_id = 0      # global id of game 0 (rank * n_games when sharded), keys the sampler's RNG
         self._is_max_local = self._is_max_global = None   # params.global_is_max: per-rank / all-rank IS normalisers
+        # params.actor_lag = 1 (asynchronous actor): see update_begin() and hanabi_hip.selfplay for the ordering rules
+        self.actor_lag = int(params.actor_lag)
+        if self.actor_lag and not (self._fused and use_fused_learner and params.use_priority and len(params.layers) == 1):
+            raise ValueError("actor_lag=1 needs the HIP fused learner (GPU, C51 head, one hidden layer) with prioritized replay")
+        self._support0 = None       # atoms[0], contiguous (the support every action shares)
+        self._pending_fills = []    # actor_lag: (start, rows) of inserts whose sum-tree leaves the NEXT update_begin() sets
+        self.gathered_ev = None     # actor_lag: recorded when an update has finished reading the replay rings
 
     @property
     def last_loss(self):
@@ -292,14 +299,18 @@ class DQNAgent:
             self.online.resample()
             self._eff_cache = None
         eff = self._effective_weights()
-        fl = self._fl
+        fl = self._fused_learner() if self.actor_lag else self._fl
         if fl is not None and fl.actor is not None and obs.dtype in (torch.int8, torch.int32) and self.use_mfma_actor:
             # hand-written MFMA path: int8 or bit-packed observations in, actions out; no bf16 copy of the observations and no
             # logits in HBM
-            fl.pack_actor()
+            wset = fl.acting_set()
             self._draws += 1
-            return fl.actor.act(obs.contiguous(), legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
-                                self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
+            if self._support0 is None:
+                self._support0 = self.atoms[0].contiguous()
+            return fl.actor.act(obs.contiguous(), legal.to(torch.int8).contiguous(), self._support0, epsilon,
+                                self.params.seed + 0x9E3779B9, self._draws, self.first_game_id, s=wset)
+        if self.actor_lag:
+            raise RuntimeError("actor_lag=1: the MFMA actor takes int8 or bit-packed observations")
         obs = self._obs_int8(obs)
         cd = eff[0][0].dtype
         kp = eff[0][0].shape[0]                     # first-layer K, possibly padded (FusedLearner keeps padded operands)
@@ -375,7 +386,13 @@ class DQNAgent:
             buf, n = self.experience, obs.shape[0]
             start = buf.oldest_entry
             if self.params.use_priority:  # new leaves enter at max priority (priority_buffer.py:29-32)
-                buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
+                if self.actor_lag:
+                    # asynchronous actor: the sum tree is written ONLY on the stream the updates run on. The leaves of these
+                    # rows are set by the next update_begin(), i.e. after the priority write-back of the update in flight and
+                    # before the next sampling: the same order of tree writes as with actor_lag=0.
+                    self._pending_fills.append((start, n))
+                else:
+                    buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
             ops.replay_insert(self.last_obs, self._obs_store(obs).contiguous(), legal.to(torch.int8).contiguous(),
                               self._vec(actions, torch.int32).contiguous(), self._vec(rewards, torch.float32).contiguous(),
                               self._vec(step_types, torch.int8).contiguous(), buf, start)
@@ -408,8 +425,28 @@ class DQNAgent:
     # replay insert, policy and env step between the two calls, so the ~3.4 MB gradient exchange over xGMI hides
     # behind ~0.2 ms of independent work. With one rank the pair is exactly update() — and, under HIP graphs, the whole
     # update (Adam included) is one graph launched by update_begin(): do not let anything read the weights between the two.
+    def apply_pending_fills(self):
+        """actor_lag: set the sum-tree leaves of the rows inserted since the last update (on the CURRENT stream, which must be
+        the one the updates run on)."""
+        for start, n in self._pending_fills:
+            self.experience.sum_tree.fill_range_dev(start, n, self.experience._max_priority)
+        self._pending_fills.clear()
+
+    def _pre_gather(self):
+        """actor_lag: sampling + replay gather as their own launch in front of the (captured) rest of the update, followed by
+        an event: from there on the update no longer reads the rings, and the acting stream may overwrite their oldest rows."""
+        fl = self._fused_learner()
+        fl.sample_and_gather(self.params.seed + 0x51ED270B + 0x9E3779B1 * self.first_game_id)
+        if self.gathered_ev is None:
+            from hanabi_hip import _capi as K
+
+            self.gathered_ev = K.Event()
+        self.gathered_ev.record()
+
     def update_begin(self):
         assert self._pending is None, "update_finish() of the previous update has not been called"
+        if self.actor_lag:
+            self.apply_pending_fills()
         self.experience.sync_size()
         beta = float(self.params.beta_is(self.train_step))
         if beta != self._beta_host:  # device scalar read inside the captured graph: refreshed only when it changes
@@ -418,9 +455,13 @@ class DQNAgent:
         if self._graphs_enabled():
             if self._graph1 is None:
                 self._capture_update_graphs()
+            if self.actor_lag:
+                self._pre_gather()
             self._graph1.replay()
             part2_args = None
         else:
+            if self.actor_lag:
+                self._pre_gather()
             self.last_loss, indices, new_prios = self._update_part1()
             part2_args = (indices, new_prios)
         self._pending = (self._allreduce_gradients(async_op=True), part2_args)
@@ -438,7 +479,7 @@ class DQNAgent:
             self._update_part2(*part2_args)
         self._eff_cache = None
         if self._fl is not None:
-            self._fl.actor_stale = True  # Adam rewrote the effective weights: repack before the next act
+            self._fl.weights_updated()  # Adam rewrote the effective weights: the actor's copies follow (lazily, or now: actor_lag)
         if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
             self._sync_target()
         self.train_step += 1
@@ -541,7 +582,9 @@ class DQNAgent:
                 self.target.resample()
                 fl.refresh_effective()
                 fl.refresh_target()
-            if self.params.use_priority and "_sample_indices" not in self.__dict__:
+            if self.actor_lag:
+                indices, prios, gathered = fl._idx, fl._prob, True   # filled by _pre_gather(), outside the captured part
+            elif self.params.use_priority and "_sample_indices" not in self.__dict__:
                 # PER: tree descent and replay gather in one launch (same draws as _sample_indices below)
                 indices, prios = fl.sample_and_gather(self.params.seed + 0x51ED270B + 0x9E3779B1 * self.first_game_id)
                 gathered = True
@@ -578,6 +621,8 @@ class DQNAgent:
             self.experience.update_priorities_dev(indices, new_prios)
 
     def _update_eager(self):
+        if self.actor_lag:
+            self._pre_gather()
         self.last_loss, indices, new_prios = self._update_part1()
         self._finish_allreduce(self._allreduce_gradients(async_op=False))
         self._update_part2(indices, new_prios)
@@ -631,7 +676,7 @@ class DQNAgent:
         self._gen.set_state(snap["gen"])
         self._last_loss = snap["last_loss"]
         self._eff_cache = None
-        if self._fl is not None:
+        if self._fl is not None and not self.actor_lag:   # (actor_lag: the warm-up updates never touch the actor's weight sets)
             self._fl.actor_stale = True
 
     def _capture_update_graphs(self):
@@ -749,6 +794,11 @@ class DQNAgent:
                                moments={f"{li}.{name}.{k}": t.cpu() for (li, name), mv in fl.state.items()
                                         for k, t in zip("mv", mv)},
                                eff=[t.cpu() for pair in fl.eff for t in pair], trg=[t.cpu() for pair in fl.trg for t in pair])
+            if self.actor_lag:   # the set the policy reads is one update behind `eff`: it is state of its own
+                fl.pack_actor()
+                sd["fused"]["actor_sets"] = [t.cpu() for st in fl.actor.sets for t in st]
+                sd["fused"]["n_packed"] = fl.n_packed
+                sd["pending_fills"] = [list(x) for x in self._pending_fills]
         else:
             sd["optimizer"] = self.optimizer.state_dict()
         return sd
@@ -782,6 +832,13 @@ class DQNAgent:
                 for dst, src in zip([t for pair in fl.trg for t in pair], f["trg"]):
                     dst.copy_(src)
                 fl.actor_stale = True
+                if self.actor_lag:
+                    if "actor_sets" not in f:
+                        raise ValueError("checkpoint was written with actor_lag=0")
+                    for dst, src in zip([t for st in fl.actor.sets for t in st], f["actor_sets"]):
+                        dst.copy_(src)
+                    fl.n_packed, fl.packed_ev, fl.actor_stale = int(f["n_packed"]), [None, None], False
+                    self._pending_fills = [tuple(x) for x in sd.get("pending_fills", [])]
             else:
                 self.optimizer.load_state_dict(sd["optimizer"])
                 self._trg_cache = None

@@ -103,6 +103,10 @@ SIGNATURES = {
     "hb_env_set_async_refill": (C.c_int, [_P, _I32]),
     "hb_env_set_refill_period": (C.c_int, [_P, _I32]),
     "hb_env_set_profile_events": (C.c_int, [_P, _P, _P]),
+    "hb_event_create": (C.c_int, [C.POINTER(_P)]),
+    "hb_event_destroy": (C.c_int, [_P]),
+    "hb_event_record": (C.c_int, [_P, _P]),
+    "hb_stream_wait_event": (C.c_int, [_P, _P]),
     "hb_tree_create": (C.c_int, [_I64, C.POINTER(_P)]),
     "hb_tree_destroy": (C.c_int, [_P]),
     "hb_tree_capacity": (_I64, [_P]),
@@ -136,6 +140,8 @@ SIGNATURES = {
     "hb_actor_hidden_packed": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
     "hb_actor_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P]),
     "hb_policy_select": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _U64, _U64, _I64, _P, _P]),
+    "hb_actor_act": (C.c_int, [_P, _I32, _P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _P, C.c_float, _U64, _U64, _I64,
+                               _P, _P]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }
@@ -182,3 +188,41 @@ def current_stream():
 def dptr(t):
     """Raw device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Event:
+    """hipEvent_t (timing off) through the C-ABI: record(stream) / wait(stream) take raw hipStream_t values (c_void_p or
+    int; None = torch's current stream). ~1 us per call where torch.cuda.Event's methods cost ~8 us."""
+
+    __slots__ = ("h", "_lib", "recorded")
+
+    def __init__(self):
+        self._lib = lib()
+        h = C.c_void_p()
+        check(self._lib.hb_event_create(C.byref(h)))
+        self.h = h
+        self.recorded = False
+
+    def record(self, stream=None):
+        check(self._lib.hb_event_record(self.h, current_stream() if stream is None else stream))
+        self.recorded = True
+
+    def wait(self, stream=None):
+        """Make `stream` wait for the most recent record() (no-op if never recorded)."""
+        if self.recorded:
+            check(self._lib.hb_stream_wait_event(current_stream() if stream is None else stream, self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.hb_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+def set_stream(stream):
+    """torch.cuda.set_stream without the device-index plumbing of the context manager (~1 us instead of ~20 us for
+    `with torch.cuda.stream(s)`). The caller restores the previous stream itself."""
+    import torch
+
+    torch._C._cuda_setStream(stream_id=stream.stream_id, device_index=stream.device_index, device_type=stream.device_type)

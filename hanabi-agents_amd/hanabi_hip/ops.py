@@ -50,34 +50,45 @@ class ActorMFMA:
     """The actor's forward pass on the hand-written MFMA kernels (csrc/actor.hip): packed (transposed) copies of
     the effective weights plus the scratch buffers; `pack` after every weight change, `act` per step."""
 
-    def __init__(self, obs_len, hidden, n_actions, n_atoms, k_pad, device):
+    def __init__(self, obs_len, hidden, n_actions, n_atoms, k_pad, device, n_sets=1):
         assert k_pad % 64 == 0 and k_pad >= obs_len and hidden % 256 == 0 and 2 <= n_atoms <= 256
         self.obs_len, self.hidden, self.n_actions, self.n_atoms, self.k_pad = obs_len, hidden, n_actions, n_atoms, k_pad
         self.group_actions = 256 // n_atoms
         groups = -(-n_actions // self.group_actions)
         bf = dict(dtype=torch.bfloat16, device=device)
-        self.w1t = torch.zeros(hidden, k_pad, **bf)
-        self.b1 = torch.zeros(hidden, dtype=torch.float32, device=device)
-        self.w2t = torch.zeros(groups * 256, hidden, **bf)
-        self.b2 = torch.zeros(groups * 256, dtype=torch.float32, device=device)
+        # n_sets > 1: double-buffered weights (params.actor_lag): the actor reads one set while the learner packs the other
+        self.n_sets = int(n_sets)
+        self.sets = [(torch.zeros(hidden, k_pad, **bf), torch.zeros(hidden, dtype=torch.float32, device=device),
+                      torch.zeros(groups * 256, hidden, **bf), torch.zeros(groups * 256, dtype=torch.float32, device=device))
+                     for _ in range(self.n_sets)]
+        self.w1t, self.b1, self.w2t, self.b2 = self.sets[0]
         self.h = self.q = self.actions = None
+        self._jobs = {}
+        self._set_ptrs = [tuple(t.data_ptr() for t in st) for st in self.sets]
 
     @staticmethod
     def supports(obs_len, hidden, n_atoms, k_pad, dtype):
         return dtype == torch.bfloat16 and k_pad % 64 == 0 and hidden % 256 == 0 and 2 <= n_atoms <= 256
 
-    def pack(self, w1, b1, w2, b2):
-        """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K]."""
-        ak = self.n_actions * self.n_atoms
-        jobs = (K.HbPackJob * 2)()
-        for j, (w, b, wt, bo, k_rows, n_cols, group, kp) in enumerate((
-                (w1, b1, self.w1t, self.b1, self.obs_len, self.hidden, 0, self.k_pad),
-                (w2, b2, self.w2t, self.b2, self.hidden, ak, self.group_actions * self.n_atoms, self.hidden))):
-            jobs[j].w, jobs[j].bias, jobs[j].wt, jobs[j].bias_out = w.data_ptr(), b.data_ptr(), wt.data_ptr(), bo.data_ptr()
-            jobs[j].k_rows, jobs[j].n_cols, jobs[j].w_ld, jobs[j].group_cols, jobs[j].k_pad = k_rows, n_cols, w.stride(0), group, kp
+    def pack(self, w1, b1, w2, b2, s=0):
+        """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K];
+        s: the weight set written."""
+        key = (s, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w1.stride(0), w2.stride(0))
+        jobs = self._jobs.get(key)
+        if jobs is None:   # (the learner packs the same persistent operands after every update: build the job table once)
+            ak = self.n_actions * self.n_atoms
+            w1t, b1o, w2t, b2o = self.sets[s]
+            jobs = (K.HbPackJob * 2)()
+            for j, (w, b, wt, bo, k_rows, n_cols, group, kp) in enumerate((
+                    (w1, b1, w1t, b1o, self.obs_len, self.hidden, 0, self.k_pad),
+                    (w2, b2, w2t, b2o, self.hidden, ak, self.group_actions * self.n_atoms, self.hidden))):
+                jobs[j].w, jobs[j].bias, jobs[j].wt, jobs[j].bias_out = w.data_ptr(), b.data_ptr(), wt.data_ptr(), bo.data_ptr()
+                jobs[j].k_rows, jobs[j].n_cols, jobs[j].w_ld, jobs[j].group_cols, jobs[j].k_pad = k_rows, n_cols, w.stride(0), group, kp
+            if len(self._jobs) < 16:
+                self._jobs[key] = jobs
         K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))   # both layers in one launch
 
-    def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0):
+    def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0, s=0):
         n = obs.shape[0]
         packed = obs.dtype == torch.int32
         assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
@@ -87,11 +98,9 @@ class ActorMFMA:
             self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
         actions = torch.empty(n, dtype=torch.int32, device=obs.device)
-        L, s = K.lib(), K.current_stream()
-        hidden = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden   # bit rows are unpacked while staged into LDS
-        K.check(hidden(K.dptr(obs), n, self.obs_len, K.dptr(self.w1t), self.k_pad, K.dptr(self.b1), self.hidden, K.dptr(self.h), s))
-        K.check(L.hb_actor_q(K.dptr(self.h), n, self.hidden, K.dptr(self.w2t), K.dptr(self.b2), K.dptr(support), self.n_actions,
-                             self.n_atoms, K.dptr(self.q), s))
-        K.check(L.hb_policy_select(K.dptr(self.q), K.dptr(legal), n, self.n_actions, float(epsilon), int(seed), int(draw),
-                                   int(first_game_id), K.dptr(actions), s))
+        w1p, b1p, w2p, b2p = self._set_ptrs[s]
+        K.check(K.lib().hb_actor_act(obs.data_ptr(), 1 if packed else 0, legal.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p,
+                                     self.hidden, self.h.data_ptr(), w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,
+                                     self.q.data_ptr(), float(epsilon), int(seed), int(draw), int(first_game_id),
+                                     actions.data_ptr(), K.current_stream()))   # hidden GEMM, q GEMM + C51 expectation, selection
         return actions

@@ -53,9 +53,13 @@ class SelfPlaySession:
         self._dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         # one learner stream per agent: seat A's update (launched at step t, needed at t + P) runs beside seat B's (t + 1):
         # the two latency-bound kernel chains interleave instead of queueing one behind the other
-        self._stream_per_agent = self._dp if stream_per_agent is None else bool(stream_per_agent)
+        # (default: data-parallel runs, and asynchronous actors — there the acting stream waits for the seat's own `gathered`
+        # event only, which on a shared learner stream would sit behind the OTHER seat's whole update: 0.137 vs 0.150 ms per step)
+        lagging = any(getattr(a, "actor_lag", 0) for a in agents)
+        self._stream_per_agent = (self._dp or lagging) if stream_per_agent is None else bool(stream_per_agent)
         self._lstreams = {}
         self._update_done = {}  # agent id -> event recorded on the learner stream after its last update
+        self._acted_ev, self._done_ev = {}, {}   # persistent events (creating one costs more than recording it)
         self.env_steps = 0
         self.grad_steps = 0
         self._inflight = None  # agent whose update_begin() has run but not its update_finish() (data-parallel overlap)
@@ -72,7 +76,15 @@ class SelfPlaySession:
                 self._main, self._main_raw = torch.cuda.current_stream(), raw
             main = self._main
         if main is not None and id(agent) in self._update_done:
-            main.wait_event(self._update_done.pop(id(agent)))  # its replay / weights are being written by that update
+            if getattr(agent, "actor_lag", 0):
+                # asynchronous actor (params.actor_lag = 1): the acting stream waits only until the seat's update in flight has
+                # READ the replay rings (its first launch); the weights come from the actor's other buffer and the sum tree is
+                # written on the learner stream alone
+                self._update_done.pop(id(agent))
+                if agent.gathered_ev is not None:
+                    agent.gathered_ev.wait(raw)
+            else:
+                self._update_done.pop(id(agent)).wait(raw)  # its replay / weights are being written by that update
         # [0]: the rich observation source for agents with requires_vectorized_observation() False (rule-based
         # partners read the env's state rows); [1]: the vectorised (obs, legal) pair the DQN agents use
         observations = (env, (env.net_obs, env.legal))   # packed env: the bit rows, which the agents take as they are
@@ -90,21 +102,30 @@ class SelfPlaySession:
             # The policy has read the weights: the learner may overwrite them from here on. Recorded AFTER the env step:
             # releasing the learner before it is throughput-neutral (0.194 ms either way) but makes the HBM-bound env
             # kernel share the chip with the update's first kernels (18 us per launch instead of 14).
-            acted = torch.cuda.Event()
-            acted.record(main)
+            acted = self._acted_ev.get(seat)   # (re-recording an event does not disturb waits already enqueued on it)
+            if acted is None:
+                acted = self._acted_ev[seat] = K.Event()
+            acted.record(raw)
         self.env_steps += env.n
         if self.learner_stream is None:
             self._train_inline(agent, seat, train)
         elif train and seat in self.train_seats and self._ready(agent):
             ls = self._learner_stream_of(agent)
-            with torch.cuda.stream(ls):
-                ls.wait_event(acted)
+            lraw = ls.cuda_stream
+            K.set_stream(ls)   # (the context manager costs ~20 us of Python per use)
+            try:
+                acted.wait(lraw)
                 for _ in range(self.updates_per_step):
                     agent.update_begin()
                     agent.update_finish()
                     self.grad_steps += 1
-                done = torch.cuda.Event()
-                done.record(ls)
+                done = self._done_ev.get(id(agent))
+                if done is None:
+                    done = self._done_ev[id(agent)] = K.Event()
+                if not getattr(agent, "actor_lag", 0):   # (an asynchronous actor waits for agent.gathered_ev instead)
+                    done.record(lraw)
+            finally:
+                K.set_stream(main)
             self._update_done[id(agent)] = done
         self.t += 1
 
@@ -147,10 +168,23 @@ class SelfPlaySession:
             self._inflight.update_finish()
             self._inflight = None
         if self.learner_stream is not None:
+            if any(getattr(a, "_pending_fills", None) for a in self.agents):
+                # (actor_lag) leaves of rows inserted after the last update: set them where the tree is written
+                cur = torch.cuda.current_stream()
+                for a in self.agents:
+                    if getattr(a, "_pending_fills", None):
+                        ls = self._learner_stream_of(a)
+                        ls.wait_stream(cur)
+                        with torch.cuda.stream(ls):
+                            a.apply_pending_fills()
             torch.cuda.current_stream().wait_stream(self.learner_stream)
             for ls in self._lstreams.values():
                 torch.cuda.current_stream().wait_stream(ls)
             self._update_done.clear()
+        else:
+            for a in self.agents:
+                if getattr(a, "_pending_fills", None):
+                    a.apply_pending_fills()
 
     def run(self, steps, train=True):
         for _ in range(steps):

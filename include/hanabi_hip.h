@@ -229,6 +229,14 @@ int hb_env_set_refill_period(hb_env* env, int32_t steps);
  * begin/end timestamps rather than a pair of stream markers. NULL, NULL turns it off.      */
 int hb_env_set_profile_events(hb_env* env, void* start_event, void* stop_event);
 
+/* Stream-ordering helpers for host drivers (hipEvent_t / hipStream_t as void*): the self-play loop orders its acting
+ * and learner streams with a handful of events per step. No reference counterpart (the reference is single-threaded
+ * host code); they exist so that a binding needs no HIP runtime binding of its own. Events are created with timing off. */
+int hb_event_create(void** event_out);
+int hb_event_destroy(void* event);
+int hb_event_record(void* event, void* stream);
+int hb_stream_wait_event(void* stream, void* event);
+
 /* ---- GPU-resident sum tree ------------------------------------------------------------
  * Replaces sum_tree.SumTreef (sum_tree/sum_tree/include/sum_tree.h:22-130 through
  * sum_tree/sum_tree/src/sum_tree_py.cc:9-22). Flat fp32 heap array in HBM: node 1 is the
@@ -487,6 +495,13 @@ int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2
                const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, void* stream);
 int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_games, int32_t n_actions, float epsilon,
                      uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
+
+/* hb_actor_hidden[_packed] + hb_actor_q + hb_policy_select behind one call (one binding round trip per policy call instead of
+ * three); obs_is_packed != 0: obs_dev is the bit-row form. Same argument rules as the three functions.                     */
+int hb_actor_act(const void* obs_dev, int32_t obs_is_packed, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len,
+                 const void* w1t_dev, int32_t k_pad, const float* b1_dev, int32_t hidden, void* h_dev, const void* w2t_dev,
+                 const float* b2_dev, const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon,
+                 uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,9 +9,11 @@ from hanabi_hip.selfplay import SelfPlaySession
 n = 32768
 flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
 env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=1234, packed=True)
-params = RlaxRainbowParams(compute_dtype="bfloat16", mask_terminal=True, packed_obs=True)
+lag = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+spa = bool(int(sys.argv[2])) if len(sys.argv) > 2 else None
+params = RlaxRainbowParams(compute_dtype="bfloat16", mask_terminal=True, packed_obs=True, actor_lag=lag)
 agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s), device="cuda") for s in (0, 1)]
-sess = SelfPlaySession(env, agents)
+sess = SelfPlaySession(env, agents, stream_per_agent=spa)
 for _ in range(60):
     sess.step()
 torch.cuda.synchronize()
