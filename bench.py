@@ -189,7 +189,8 @@ def cpu_baseline_learner(args, obs_len, n_actions):
     try:
         n = 4096
         params = RlaxRainbowParams(use_priority=False, experience_buffer_size=n, mask_terminal=True, seed=7)
-        agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_actions), params, device="cpu")
+        # process_group=False: this agent lives on rank 0 only and must not all-reduce with the job's other ranks
+        agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_actions), params, device="cpu", process_group=False)
         g = torch.Generator().manual_seed(0)
         o1 = (torch.rand(n, obs_len, generator=g) < 0.3).to(torch.int8)
         o2 = (torch.rand(n, obs_len, generator=g) < 0.3).to(torch.int8)
@@ -277,6 +278,10 @@ def main():
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("HB_BENCH_WATCHDOG"):   # debugging aid: dump every thread's Python stack and exit after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["HB_BENCH_WATCHDOG"]), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.launch_check:
@@ -484,10 +489,15 @@ def main():
             and not args.no_async_variant and env.packed):
         line["async_actor"] = async_variant(args, rank, world, device, n)   # (every rank: it holds collectives)
     if rank == 0 and not args.no_cpu_baseline:
+        note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)   # progress on stderr; stdout carries the ONE JSON line
+        note(f"timed region done ({dt / args.steps * 1e3:.4f} ms per step); timing the CPU baselines on rank 0")
         line["cpu_baseline"] = cpu_baseline(args)
+        note("cpu_baseline (env port) done")
         if not args.env_only:
             line["cpu_baseline_learner"] = cpu_baseline_learner(args, env.obs_len, env.num_actions)
+            note("cpu_baseline_learner done")
         line["cpu_baseline_sum_tree"] = sum_tree_baseline(device)
+        note("cpu_baseline_sum_tree done")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

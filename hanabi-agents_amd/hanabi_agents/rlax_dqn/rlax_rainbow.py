@@ -125,7 +125,9 @@ class DQNAgent:
         self.params = params
         self.device = torch.device(device) if device is not None else torch.device(
             "cuda" if torch.cuda.is_available() else "cpu")
-        self.process_group = process_group  # torch.distributed group for data-parallel gradient all-reduce
+        # torch.distributed group for the data-parallel gradient all-reduce (None: the default group when one is initialised;
+        # False: never — a purely local agent inside a distributed job, e.g. a baseline timed on one rank)
+        self.process_group = process_group
         n_games, obs_len = _shape_of(observation_spec)
         self.n_actions = int(action_spec.num_values)
         self.obs_len = obs_len
@@ -712,6 +714,8 @@ class DQNAgent:
     def _dp_world(self):
         import torch.distributed as dist
 
+        if self.process_group is False:   # explicitly local: an agent that must not join the job's collectives
+            return 1
         if self.process_group is None and not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(self.process_group)

@@ -48,7 +48,16 @@ def _worker(rank, world, port, out):
     g = torch.cat([x.reshape(-1) for x in torch.autograd.grad(loss, list(agent.online.parameters()))])
     agent.update()
     w = torch.cat([p.detach().reshape(-1) for p in agent.online.parameters()])
-    torch.save({"grad": g, "weights": w}, os.path.join(out, f"r{rank}.pt"))
+    extra = {}
+    if rank == 0:
+        # a purely local agent inside the distributed job (bench.py's CPU learner baseline lives on rank 0 only): with
+        # process_group=False its update must not enter a collective — the other rank never would, and the job would hang
+        solo = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cpu", process_group=False)
+        solo.add_experience_first((None, (o1, legal)), np.zeros(n))
+        solo.add_experience((None, (o2, legal)), rng.integers(0, n_act, n), rng.integers(0, 2, n).astype(float), np.ones(n))
+        solo.update()
+        extra["solo_world"] = solo._dp_world()
+    torch.save({"grad": g, "weights": w, **extra}, os.path.join(out, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,6 +68,7 @@ def test_gradient_allreduce_keeps_ranks_identical(tmp_path):
     r = [torch.load(tmp_path / f"r{i}.pt") for i in range(world)]
     assert not torch.allclose(r[0]["grad"], r[1]["grad"])            # shards differ
     assert torch.equal(r[0]["weights"], r[1]["weights"])              # replicas stay in lock step
+    assert r[0]["solo_world"] == 1                                    # (and the rank-0-only local agent finished its update)
     # the applied step is Adam on the MEAN gradient: first Adam step = -lr * sign-ish(g_mean)
     from oracle import learner_oracle as LO
 
