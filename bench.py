@@ -61,6 +61,7 @@ def _parse():
     ap.add_argument("--actor-lag", type=int, default=0, choices=(0, 1),
                     help="1: asynchronous actor (RlaxRainbowParams.actor_lag): double-buffered actor weights, the acting stream "
                          "never waits for an update; 0 (default): the reference's synchronous semantics")
+    ap.add_argument("--main-priority", type=int, default=0, help="HIP priority of the acting stream (-1: high; default: the default stream)")
     ap.add_argument("--no-async-variant", action="store_true", help="skip the second, asynchronous-actor measurement")
     ap.add_argument("--prime", type=int, default=24,
                     help="untimed SETUP steps before the W warm-up steps: the first updates capture the HIP graphs, pick the "
@@ -347,6 +348,8 @@ def main():
 
     act = torch.empty(n, dtype=torch.int32, device=device)
     draw = [0]
+    if main_stream is None and args.main_priority != 0:
+        main_stream = torch.cuda.Stream(device=device, priority=args.main_priority)
     if main_stream is not None:
         main_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_stream)

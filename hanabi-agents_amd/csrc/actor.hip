@@ -66,6 +66,14 @@ struct GemmArgs {
   const float* support;
   float* q;             // [M, n_actions]
   int n_actions, n_atoms, group_actions;
+  // MODE 1 with the action selection fused in (hb_actor_q_select): the LAST of a row tile's column-group workgroups to finish
+  // (ticket counter per row tile) selects the actions of the tile's rows
+  const int8_t* legal;          // [M, n_actions]; NULL: q values only
+  int32_t* actions;             // [M]
+  unsigned int* tickets;        // [row tiles], zero before the first launch; the selecting workgroup re-arms its counter
+  float epsilon;
+  unsigned long long seed, draw;
+  long long first_gid;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
@@ -120,6 +128,62 @@ __device__ __forceinline__ float c51_expectation(const uint2* __restrict__ p8, c
 __device__ __forceinline__ uint32_t bits2_bf16(uint32_t b, int p) {
   const uint32_t t = (b >> (2 * p)) & 3u;
   return __umul24((t | (t << 15)) & 0x00010001u, 0x3F80u);
+}
+
+__device__ __forceinline__ void store_q(const GemmArgs& a, long long idx, float v) {
+  if (a.legal) __hip_atomic_store(a.q + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by another workgroup of this launch
+  else a.q[idx] = v;
+}
+
+// The selection rule (policy_kernel, policy.hip) for `ng` consecutive games starting at g0, one lane per game, run by the
+// first `cap` of `nthreads` threads of a workgroup: q and legal rows are fetched with coalesced loads into LDS (row stride
+// A | 1: conflict-free), then ONE scan per game builds the legal mask, the maximum and its tie set together.
+// sq: cap * (A | 1) floats followed by as many bytes. COHERENT: q was written by OTHER workgroups of the running kernel:
+// read it with device-scope loads.
+template <int AT, bool COHERENT>
+__device__ __forceinline__ void select_rows(const float* __restrict__ q, const int8_t* __restrict__ legal, long long g0, int ng, int A_rt,
+                                            float epsilon, unsigned long long seed, unsigned long long draw, long long first_gid,
+                                            int32_t* __restrict__ actions, float* sq, int cap, int tid, int nthreads) {
+  const int A = AT > 0 ? AT : A_rt;
+  const int ld = A | 1;
+  int8_t* sl = reinterpret_cast<int8_t*>(sq + cap * ld);
+  // the Philox draw does not depend on the loads: issue it while they are in flight
+  const long long g = g0 + tid;
+  const unsigned long long gid = static_cast<unsigned long long>(first_gid + g);
+  uint32_t r[4];
+  hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),
+                    static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+  for (int e = tid; e < ng * A; e += nthreads) {
+    const int gg = e / A, i = e - gg * A;
+    sq[gg * ld + i] = COHERENT ? __hip_atomic_load(q + g0 * A + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : q[g0 * A + e];
+    sl[gg * ld + i] = legal[g0 * A + e];
+  }
+  __syncthreads();
+  if (tid >= ng) return;
+  const float* qr = sq + tid * ld;
+  const int8_t* lr = sl + tid * ld;
+  float best = -INFINITY;
+  unsigned long long legal_mask = 0, ties = 0;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    const float v = qr[i];
+    if (lr[i] != 0) {
+      legal_mask |= 1ull << i;
+      if (v > best) { best = v; ties = 1ull << i; }
+      else if (v == best) ties |= 1ull << i;
+    }
+  }
+  const float u = static_cast<float>(r[0] >> 8) * (1.0f / 16777216.0f);
+  unsigned long long pool = (u < epsilon) ? legal_mask : ties;
+  if (pool == 0) pool = legal_mask;
+  int pick = 0;
+  const int c = __popcll(pool);
+  if (c > 0) {
+    int k = static_cast<int>(__umulhi(r[1], static_cast<uint32_t>(c)));
+    while (k-- > 0) pool &= pool - 1;
+    pick = __ffsll(static_cast<long long>(pool)) - 1;
+  }
+  actions[g] = pick;
 }
 
 // MODE 0: hidden layer from int8 observations; MODE 1: output layer + C51 expectation; MODE 2: hidden layer from bit-packed
@@ -294,7 +358,7 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
         else if (lead == 1) qv = c51_expectation<51, 1>(p8, a.support);
         else if (lead == 2) qv = c51_expectation<51, 2>(p8, a.support);
         else qv = c51_expectation<51, 3>(p8, a.support);
-        if (row0 + r < a.m) a.q[(row0 + r) * a.n_actions + first_action + al] = qv;
+        if (row0 + r < a.m) store_q(a, (row0 + r) * a.n_actions + first_action + al, qv);
         continue;
       }
       float mx = -INFINITY;
@@ -307,7 +371,34 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
       }
       qv = t / s / static_cast<float>(K);
 #endif
-      if (row0 + r < a.m) a.q[(row0 + r) * a.n_actions + first_action + al] = qv;
+      if (row0 + r < a.m) store_q(a, (row0 + r) * a.n_actions + first_action + al, qv);
+    }
+    if (a.legal) {
+      // Action selection fused in: every workgroup publishes its q values and takes a ticket of its row tile; the one that
+      // draws the last ticket sees all n_actions values of the tile's rows and selects their actions with the rule of
+      // policy_select_kernel. One launch and one trip of the q values through a kernel boundary less on the acting stream's
+      // critical path. Coherence across XCDs (each has its own L2) comes from the accesses themselves: q is written with
+      // device-scope stores (write-through) and read back with device-scope loads, the ticket is a device-scope RMW; the
+      // ordering needs only "my stores have completed" (s_waitcnt vmcnt(0): the workgroup-scope release fence) before the
+      // barrier that precedes the RMW. Device-scope FENCES are deliberately absent: each is an L2 write-back + invalidate,
+      // and 4 096 of them per launch made the kernel 4x slower (measured: 174 us for the policy call instead of 75).
+      __shared__ int s_last;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.tickets + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1u == gridDim.y;
+        if (last) __hip_atomic_store(a.tickets + rt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {   // (workgroup-uniform)
+        const int ng = a.m - row0 < BM ? static_cast<int>(a.m - row0) : BM;
+        float* sq = reinterpret_cast<float*>(lds);
+        if (a.n_actions == 20) select_rows<20, true>(a.q, a.legal, row0, ng, 20, a.epsilon, a.seed, a.draw, a.first_gid, a.actions, sq, BM, tid, NT);
+        else if (a.n_actions == 48) select_rows<48, true>(a.q, a.legal, row0, ng, 48, a.epsilon, a.seed, a.draw, a.first_gid, a.actions, sq, BM, tid, NT);
+        else select_rows<0, true>(a.q, a.legal, row0, ng, a.n_actions, a.epsilon, a.seed, a.draw, a.first_gid, a.actions, sq, BM, tid, NT);
+      }
     }
   }
 }
@@ -537,6 +628,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackJobs jobs) 
 // contiguous in q and legal: fetched with coalesced loads into LDS (row stride A | 1: conflict-free), then ONE scan per
 // game builds the legal mask, the maximum and its tie set together. 128 games per workgroup: 256 workgroups at 32 768 games
 // (the 256-game version left half of the CUs idle and ran two dependent scans: 7.8 us alone, 11.6 us inside the loop).
+// (select_rows above is the body; hb_actor_q_select runs the same body inside the output-layer GEMM's last workgroups.)
 constexpr int SEL_T = 128;
 template <int AT>  // AT > 0: compile-time action count (unrolled scan); 0: run-time A
 __global__ __launch_bounds__(SEL_T) void policy_select_kernel(const float* __restrict__ q, const int8_t* __restrict__ legal, long long n,
@@ -546,45 +638,7 @@ __global__ __launch_bounds__(SEL_T) void policy_select_kernel(const float* __res
   const int A = AT > 0 ? AT : A_rt;
   const long long g0 = static_cast<long long>(blockIdx.x) * SEL_T;
   const int ng = n - g0 < SEL_T ? static_cast<int>(n - g0) : SEL_T;
-  const int ld = A | 1;
-  int8_t* sl = reinterpret_cast<int8_t*>(sq + SEL_T * ld);
-  // the Philox draw does not depend on the loads: issue it while they are in flight
-  const long long g = g0 + threadIdx.x;
-  const unsigned long long gid = static_cast<unsigned long long>(first_gid + g);
-  uint32_t r[4];
-  hb::philox4x32_10(static_cast<uint32_t>(draw), static_cast<uint32_t>(draw >> 32), static_cast<uint32_t>(gid),
-                    static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
-  for (int e = threadIdx.x; e < ng * A; e += SEL_T) {
-    const int gg = e / A, i = e - gg * A;
-    sq[gg * ld + i] = q[g0 * A + e];
-    sl[gg * ld + i] = legal[g0 * A + e];
-  }
-  __syncthreads();
-  if (static_cast<int>(threadIdx.x) >= ng) return;
-  const float* qr = sq + threadIdx.x * ld;
-  const int8_t* lr = sl + threadIdx.x * ld;
-  float best = -INFINITY;
-  unsigned long long legal_mask = 0, ties = 0;
-#pragma unroll
-  for (int i = 0; i < A; ++i) {
-    const float v = qr[i];
-    if (lr[i] != 0) {
-      legal_mask |= 1ull << i;
-      if (v > best) { best = v; ties = 1ull << i; }
-      else if (v == best) ties |= 1ull << i;
-    }
-  }
-  const float u = static_cast<float>(r[0] >> 8) * (1.0f / 16777216.0f);
-  unsigned long long pool = (u < epsilon) ? legal_mask : ties;
-  if (pool == 0) pool = legal_mask;
-  int pick = 0;
-  const int c = __popcll(pool);
-  if (c > 0) {
-    int k = static_cast<int>(__umulhi(r[1], static_cast<uint32_t>(c)));
-    while (k-- > 0) pool &= pool - 1;
-    pick = __ffsll(static_cast<long long>(pool)) - 1;
-  }
-  actions[g] = pick;
+  select_rows<AT, false>(q, legal, g0, ng, A, epsilon, seed, draw, first_gid, actions, sq, SEL_T, static_cast<int>(threadIdx.x), SEL_T);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -656,8 +710,9 @@ int hb_actor_hidden_packed(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t
   return HB_OK;
 }
 
-int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev, const float* support_dev,
-               int32_t n_actions, int32_t n_atoms, float* q_dev, void* stream) {
+static int launch_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev, const float* support_dev,
+                    int32_t n_actions, int32_t n_atoms, float* q_dev, const int8_t* legal_dev, float epsilon, uint64_t seed, uint64_t draw,
+                    int64_t first_game_id, int32_t* actions_dev, uint32_t* tickets_dev, void* stream) {
   if (!h_dev || !w2t_dev || !b2_dev || !support_dev || !q_dev) return fail(HB_ERR_INVALID, "null argument");
   if (n_rows <= 0) return HB_OK;
   if (hidden < BK || hidden % BK) return fail(HB_ERR_INVALID, "hidden must be a multiple of 64");
@@ -670,10 +725,22 @@ int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2
   a.group_actions = 256 / n_atoms;
   const int groups = (n_actions + a.group_actions - 1) / a.group_actions;
   const dim3 grid(static_cast<unsigned>((n_rows + BM - 1) / BM), static_cast<unsigned>(groups));
+  if (legal_dev) {   // selection fused into the GEMM's last workgroups (first form only)
+    if (!actions_dev || !tickets_dev) return fail(HB_ERR_INVALID, "null argument");
+    if (n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64");
+    a.legal = legal_dev; a.actions = actions_dev; a.tickets = tickets_dev; a.epsilon = epsilon;
+    a.seed = seed; a.draw = draw; a.first_gid = first_game_id;
+  }
   if (use_first_form()) hipLaunchKernelGGL((actor_gemm_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL((actor_gemm2_kernel<1>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
   return HB_OK;
+}
+
+int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev, const float* support_dev,
+               int32_t n_actions, int32_t n_atoms, float* q_dev, void* stream) {
+  return launch_q(h_dev, n_rows, hidden, w2t_dev, b2_dev, support_dev, n_actions, n_atoms, q_dev, nullptr, 0.f, 0, 0, 0, nullptr, nullptr,
+                  stream);
 }
 
 int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_games, int32_t n_actions, float epsilon, uint64_t seed,
@@ -696,20 +763,33 @@ int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_game
 }
 
 
-// The three launches of one policy call behind ONE entry point: a host binding pays its per-call cost (ctypes: ~5 us) once
-// instead of three times. obs_is_packed != 0: obs_dev holds bit rows (hb_actor_hidden_packed), else int8 rows.
+// One policy call behind ONE entry point: a host binding pays its per-call cost (ctypes: ~5 us) once instead of three times.
+// obs_is_packed != 0: obs_dev holds bit rows (hb_actor_hidden_packed), else int8 rows. tickets_dev != NULL (one zero-initialised
+// uint32 per 256-row tile, i.e. ceil(n_rows / 256)): the selection runs inside the output-layer GEMM (two launches); NULL:
+// hb_policy_select as a third launch. Same actions either way.
+int hb_actor_q_select(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev,
+                      const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, const int8_t* legal_dev, float epsilon,
+                      uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, uint32_t* tickets_dev, void* stream) {
+  if (!legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (tickets_dev && use_first_form())
+    return launch_q(h_dev, n_rows, hidden, w2t_dev, b2_dev, support_dev, n_actions, n_atoms, q_dev, legal_dev, epsilon, seed, draw,
+                    first_game_id, actions_dev, tickets_dev, stream);
+  const int rc = hb_actor_q(h_dev, n_rows, hidden, w2t_dev, b2_dev, support_dev, n_actions, n_atoms, q_dev, stream);
+  if (rc != HB_OK) return rc;
+  return hb_policy_select(q_dev, legal_dev, n_rows, n_actions, epsilon, seed, draw, first_game_id, actions_dev, stream);
+}
+
 int hb_actor_act(const void* obs_dev, int32_t obs_is_packed, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len, const void* w1t_dev,
                  int32_t k_pad, const float* b1_dev, int32_t hidden, void* h_dev, const void* w2t_dev, const float* b2_dev,
                  const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
-                 int64_t first_game_id, int32_t* actions_dev, void* stream) {
-  int rc = obs_is_packed ? hb_actor_hidden_packed(static_cast<const uint32_t*>(obs_dev), n_rows, obs_len, w1t_dev, k_pad, b1_dev, hidden,
-                                                  h_dev, stream)
-                         : hb_actor_hidden(static_cast<const int8_t*>(obs_dev), n_rows, obs_len, w1t_dev, k_pad, b1_dev, hidden, h_dev,
-                                           stream);
+                 int64_t first_game_id, int32_t* actions_dev, uint32_t* tickets_dev, void* stream) {
+  const int rc = obs_is_packed ? hb_actor_hidden_packed(static_cast<const uint32_t*>(obs_dev), n_rows, obs_len, w1t_dev, k_pad, b1_dev,
+                                                        hidden, h_dev, stream)
+                               : hb_actor_hidden(static_cast<const int8_t*>(obs_dev), n_rows, obs_len, w1t_dev, k_pad, b1_dev, hidden,
+                                                 h_dev, stream);
   if (rc != HB_OK) return rc;
-  rc = hb_actor_q(h_dev, n_rows, hidden, w2t_dev, b2_dev, support_dev, n_actions, n_atoms, q_dev, stream);
-  if (rc != HB_OK) return rc;
-  return hb_policy_select(q_dev, legal_dev, n_rows, n_actions, epsilon, seed, draw, first_game_id, actions_dev, stream);
+  return hb_actor_q_select(h_dev, n_rows, hidden, w2t_dev, b2_dev, support_dev, n_actions, n_atoms, q_dev, legal_dev, epsilon, seed, draw,
+                           first_game_id, actions_dev, tickets_dev, stream);
 }
 
 }  // extern "C"

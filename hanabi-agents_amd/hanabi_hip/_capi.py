@@ -140,8 +140,9 @@ SIGNATURES = {
     "hb_actor_hidden_packed": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P]),
     "hb_actor_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P]),
     "hb_policy_select": (C.c_int, [_P, _P, _I64, _I32, C.c_float, _U64, _U64, _I64, _P, _P]),
+    "hb_actor_q_select": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P, C.c_float, _U64, _U64, _I64, _P, _P, _P]),
     "hb_actor_act": (C.c_int, [_P, _I32, _P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _P, C.c_float, _U64, _U64, _I64,
-                               _P, _P]),
+                               _P, _P, _P]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }

@@ -64,6 +64,10 @@ class ActorMFMA:
         self.w1t, self.b1, self.w2t, self.b2 = self.sets[0]
         self.h = self.q = self.actions = None
         self._jobs = {}
+        # True: selection inside the output-layer GEMM (hb_actor_q_select with ticket counters). Bit-identical actions; measured
+        # r02: NOT faster (policy call 82 vs 75 us: the selecting workgroups hold their CU's LDS while they run a latency-bound
+        # tail, which delays the GEMM's second round of workgroups), so the separate hb_policy_select launch stays the default
+        self.fuse_select = False
         self._set_ptrs = [tuple(t.data_ptr() for t in st) for st in self.sets]
 
     @staticmethod
@@ -97,10 +101,12 @@ class ActorMFMA:
         if self.h is None or self.h.shape[0] != n:
             self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
+            self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
         actions = torch.empty(n, dtype=torch.int32, device=obs.device)
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
         K.check(K.lib().hb_actor_act(obs.data_ptr(), 1 if packed else 0, legal.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p,
                                      self.hidden, self.h.data_ptr(), w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,
                                      self.q.data_ptr(), float(epsilon), int(seed), int(draw), int(first_game_id),
-                                     actions.data_ptr(), K.current_stream()))   # hidden GEMM, q GEMM + C51 expectation, selection
+                                     actions.data_ptr(), self.tickets.data_ptr() if self.fuse_select else None,
+                                     K.current_stream()))   # hidden GEMM; q GEMM + C51 expectation + selection
         return actions

@@ -496,12 +496,20 @@ int hb_actor_q(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2
 int hb_policy_select(const float* q_dev, const int8_t* legal_dev, int64_t n_games, int32_t n_actions, float epsilon,
                      uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
 
-/* hb_actor_hidden[_packed] + hb_actor_q + hb_policy_select behind one call (one binding round trip per policy call instead of
- * three); obs_is_packed != 0: obs_dev is the bit-row form. Same argument rules as the three functions.                     */
+/* hb_actor_q with the action selection fused in: the last of a 256-row tile's column-group workgroups to finish (ticket
+ * counter per tile) applies hb_policy_select's rule to the tile's rows. tickets_dev: ceil(n_rows / 256) uint32, zero before the
+ * first call (the kernel re-arms them); NULL: hb_actor_q followed by hb_policy_select (two launches). Identical actions.      */
+int hb_actor_q_select(const void* h_dev, int64_t n_rows, int32_t hidden, const void* w2t_dev, const float* b2_dev,
+                      const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, const int8_t* legal_dev,
+                      float epsilon, uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev,
+                      uint32_t* tickets_dev, void* stream);
+
+/* hb_actor_hidden[_packed] + hb_actor_q_select behind one call (one binding round trip per policy call);
+ * obs_is_packed != 0: obs_dev is the bit-row form. Same argument rules as the functions it wraps.                            */
 int hb_actor_act(const void* obs_dev, int32_t obs_is_packed, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len,
                  const void* w1t_dev, int32_t k_pad, const float* b1_dev, int32_t hidden, void* h_dev, const void* w2t_dev,
                  const float* b2_dev, const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon,
-                 uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, void* stream);
+                 uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, uint32_t* tickets_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -608,3 +608,38 @@ def test_vanilla_fast_actor_matches_torch_policy():
     clear = (top2[:, 0] - top2[:, 1]) > 0.05
     assert clear.float().mean() > 0.3 and torch.equal(a8[clear].long(), masked.argmax(1)[clear])
     assert bool(legal.gather(1, a8.long()[:, None]).all())
+
+
+@pytest.mark.parametrize("n,A,atoms,hidden", [(32768, 20, 51, 512), (1000, 20, 51, 512), (300, 48, 51, 512), (700, 11, 21, 256),
+                                              (65, 6, 64, 256)])
+def test_selection_fused_into_the_q_gemm_equals_the_separate_launch(n, A, atoms, hidden):
+    """hb_actor_q_select (the last workgroup of each 256-row tile selects the tile's actions; ticket counters) against
+    hb_actor_q + hb_policy_select: identical q values and identical actions, bit for bit, over repeated calls (the counters
+    re-arm themselves), ragged row counts and the 5-player action count (10 column groups, the last one partial)."""
+    import torch
+
+    from hanabi_hip.ops import ActorMFMA
+
+    L, kp = 200, 256
+    g = torch.Generator(device="cuda").manual_seed(n + A)
+    act = ActorMFMA(L, hidden, A, atoms, kp, "cuda")
+    w1 = (torch.randn(kp, hidden, device="cuda", generator=g) * 0.08).to(torch.bfloat16)
+    w2 = (torch.randn(hidden, A * atoms, device="cuda", generator=g) * 0.08).to(torch.bfloat16)
+    b1 = (torch.randn(hidden, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    b2 = (torch.randn(A * atoms, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    act.pack(w1, b1, w2, b2)
+    support = torch.linspace(-25, 25, atoms, device="cuda")
+    for rep in range(4):
+        obs = (torch.rand(n, L, device="cuda", generator=g) < 0.35).to(torch.int8)
+        legal = (torch.rand(n, A, device="cuda", generator=g) < 0.5).to(torch.int8)
+        legal[:, 1] = 1
+        eps = 0.0 if rep % 2 == 0 else 0.25
+        act.fuse_select = True
+        a_f = act.act(obs, legal, support, eps, 77, 100 + rep, 4096).clone()
+        q_f = act.q.clone()
+        assert int(act.tickets.abs().sum()) == 0, "ticket counters were not re-armed"
+        act.fuse_select = False
+        a_s = act.act(obs, legal, support, eps, 77, 100 + rep, 4096)
+        assert torch.equal(q_f, act.q)
+        assert torch.equal(a_f, a_s), f"rep {rep}: {(a_f != a_s).sum().item()} actions differ"
+        assert bool((legal.gather(1, a_f.long()[:, None]) == 1).all())
