@@ -398,6 +398,12 @@ def main():
 
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kernel_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    # with the agent's selection fused into the kernel (SelfPlaySession.fuse_select) a launch also reads the q row (4 A bytes) and
+    # the acting seat's legal row (A bytes) per game; its 4-byte action is written instead of read
+    bytes_alone = bytes_per_step
+    fused_sel = bool(session is not None and session.fuse_select and not args.vanilla)
+    if fused_sel:
+        bytes_per_step = bytes_per_step + 5 * env.num_actions
     achieved = n * bytes_per_step / kernel_avg_s / 1e9
     line = {
         "metric": "env_steps_per_sec",
@@ -430,7 +436,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_env_step": bytes_per_step, "bytes_per_env_step_int8_form": bytes_int8_form,
-                     "observation_form": "bit-packed u32 rows (hb_env_step_packed)" if env.packed else "int8 [N, obs_len] (hb_env_step)",
+                     "observation_form": ("bit-packed u32 rows + the agent's eps-greedy selection from q (hb_env_step_select_packed: "
+                                          "+4A q, +A legal bytes read per game)" if fused_sel else
+                                          "bit-packed u32 rows (hb_env_step_packed)" if env.packed else "int8 [N, obs_len] (hb_env_step)"),
                      "env_steps_per_launch": n,
                      "avg_launch_us": kernel_avg_s * 1e6, "median_launch_us": kernel_ms[len(kernel_ms) // 2] * 1e3,
                      "kernel_only_env_steps_per_sec": n / kernel_avg_s},
@@ -460,8 +468,8 @@ def main():
         env.set_profile_events(None, None)
         alone = sorted(a.elapsed_time(b) for a, b in sa[10:])
         alone_s = sum(alone) / len(alone) / 1e3
-        line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_per_step / alone_s / 1e9,
-                                          "frac": n * bytes_per_step / alone_s / 1e9 / HBM_PEAK_GBS,
+        line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_alone / alone_s / 1e9,
+                                          "frac": n * bytes_alone / alone_s / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": bytes_alone,
                                           "note": "same kernel, env-only stepping after the timed region (50 launches)"}
         if env.packed:
             # the reference-shaped output of the same kernel (int8 [N, obs_len], SURVEY §8(d)'s 943 B per env-step), env-only

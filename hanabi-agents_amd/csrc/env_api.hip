@@ -361,6 +361,41 @@ int hb_env_step_packed(hb_env* e, const int32_t* actions_dev, uint32_t* obs_bits
   return refill_async(e, stream);
 }
 
+// hb_env_step_packed with the acting agent's epsilon-greedy selection fused into the kernel: the lane that owns game g picks
+// its move from q_dev[g, :] and sel_legal_dev[g, :] by the rule of hb_policy_select (same Philox draws: identical actions),
+// writes it to actions_out_dev[g] and applies it. One launch and one round trip of the actions less per env step.
+int hb_env_step_select_packed(hb_env* e, const float* q_dev, const int8_t* sel_legal_dev, float epsilon, uint64_t seed, uint64_t draw,
+                              int64_t first_game_id, int32_t* actions_out_dev, uint32_t* obs_bits_dev, int8_t* obs_dev,
+                              int8_t* legal_dev, float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev,
+                              int8_t* agent_step_type_dev, int8_t* score_dev, void* stream) {
+  if (!e) return fail(HB_ERR_INVALID, "null env");
+  if (!q_dev || !sel_legal_dev || !actions_out_dev) return fail(HB_ERR_INVALID, "q_dev, sel_legal_dev and actions_out_dev are required");
+  if ((reinterpret_cast<uintptr_t>(q_dev) & 15) || (reinterpret_cast<uintptr_t>(sel_legal_dev) & 3))
+    return fail(HB_ERR_ALIGN, "q_dev must be 16-byte and sel_legal_dev 4-byte aligned");
+  if (e->var->n_actions > 64) return fail(HB_ERR_INVALID, "the fused selection handles at most 64 actions");
+  if (int rc = check_out_packed(obs_bits_dev, obs_dev, legal_dev)) return rc;
+  hb::EnvArgs a{};
+  a.mode = hb::MODE_STEP;
+  a.sel_q = q_dev;
+  a.sel_legal = sel_legal_dev;
+  a.sel_actions = actions_out_dev;
+  a.sel_eps = epsilon;
+  a.sel_seed = seed;
+  a.sel_draw = draw;
+  a.sel_first_gid = first_game_id;
+  a.obs = obs_dev;
+  a.obs_bits = obs_bits_dev;
+  a.legal = legal_dev;
+  a.reward = reward_dev;
+  a.terminal = terminal_dev;
+  a.agent_reward = agent_reward_dev;
+  a.agent_step_type = agent_step_type_dev;
+  a.score = score_dev;
+  if (int rc = join_refill(e, stream)) return rc;
+  if (int rc = launch(e, a, stream)) return rc;
+  return refill_async(e, stream);
+}
+
 #ifdef HB_STAMPS
 // diagnostic library only: step once with per-wavefront phase stamps written to stamps_dev
 int hb_env_step_stamped(hb_env* e, const int32_t* actions_dev, int8_t* obs_dev, int8_t* legal_dev,

@@ -57,6 +57,15 @@ struct EnvArgs {
   int flags;
   int mode;
   int start_player;
+  // MODE_STEP with the agent's action selection fused in (hb_env_step_select*): actions == NULL and
+  //   action[g] = eps-greedy(sel_q[g, :], sel_legal[g, :]; Philox(sel_draw, sel_first_gid + g; sel_seed))
+  // by the rule of hb_policy_select (csrc/actor.hip: select_rows); the chosen uid is also written to sel_actions[g]
+  const float* sel_q;          // [n, A] expected returns
+  const int8_t* sel_legal;     // [n, A] the acting seat's legal mask (the previous step's `legal` output)
+  int32_t* sel_actions;        // [n] out
+  float sel_eps;
+  unsigned long long sel_seed, sel_draw;
+  long long sel_first_gid;
   unsigned long long* stamps;  // diagnostic builds only (-DHB_STAMPS): 12 u64 per wavefront
   hipEvent_t ev_start, ev_stop;  // host-side only: optional per-dispatch timing events
 };
@@ -252,6 +261,59 @@ __device__ __forceinline__ void expand_rows(const uint32_t* bits, int row_stride
   }
 }
 
+// The selection rule of hb_policy_select for ONE game, in the lane that owns it (same arithmetic, same draws: bit-identical
+// actions): q row and legal row fetched as 16-byte / 4-byte vectors when A allows it.
+template <int A>
+__device__ __forceinline__ int select_action(const EnvArgs& a, long long gi) {
+  float qv[A];
+  uint32_t lw[(A + 3) / 4];
+  const float* qr = a.sel_q + gi * A;
+  const int8_t* lr = a.sel_legal + gi * A;
+  if constexpr (A % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < A / 4; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(qr)[i];
+      qv[4 * i] = v.x; qv[4 * i + 1] = v.y; qv[4 * i + 2] = v.z; qv[4 * i + 3] = v.w;
+      lw[i] = reinterpret_cast<const uint32_t*>(lr)[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < (A + 3) / 4; ++i) lw[i] = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      qv[i] = qr[i];
+      lw[i >> 2] |= static_cast<uint32_t>(static_cast<uint8_t>(lr[i])) << (8 * (i & 3));
+    }
+  }
+  const unsigned long long gid = static_cast<unsigned long long>(a.sel_first_gid + gi);
+  uint32_t r[4];
+  philox4x32_10(static_cast<uint32_t>(a.sel_draw), static_cast<uint32_t>(a.sel_draw >> 32), static_cast<uint32_t>(gid),
+                static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(a.sel_seed), static_cast<uint32_t>(a.sel_seed >> 32), r);
+  float best = -INFINITY;
+  unsigned long long legal_mask = 0, ties = 0;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    const float v = qv[i];
+    if ((lw[i >> 2] >> (8 * (i & 3))) & 0xFFu) {
+      legal_mask |= 1ull << i;
+      if (v > best) { best = v; ties = 1ull << i; }
+      else if (v == best) ties |= 1ull << i;
+    }
+  }
+  const float u = static_cast<float>(r[0] >> 8) * (1.0f / 16777216.0f);
+  unsigned long long pool = (u < a.sel_eps) ? legal_mask : ties;
+  if (pool == 0) pool = legal_mask;
+  int pick = 0;
+  const int c = __popcll(pool);
+  if (c > 0) {
+    int k = static_cast<int>(__umulhi(r[1], static_cast<uint32_t>(c)));
+    while (k-- > 0) pool &= pool - 1;
+    pick = __ffsll(static_cast<long long>(pool)) - 1;
+  }
+  a.sel_actions[gi] = pick;
+  return pick;
+}
+
 // Wavefronts of a workgroup never share data here, so phases are ordered with a WAVE-level
 // barrier only: LDS operations of one wavefront execute in issue order, the fences keep the
 // compiler from moving LDS accesses across the phase boundary, and no s_barrier couples a wave
@@ -287,7 +349,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   bool mask_in = true;
   uint4 nd[4];  // this game's pre-shuffled next deck (64 B), in flight while the rules run; used only on a re-deal
   if (active) {
-    if (mode == MODE_STEP) uid_in = a.actions[gi];
+    if (mode == MODE_STEP) uid_in = a.sel_q ? select_action<K::A>(a, gi) : a.actions[gi];
     if (mode == MODE_RESET && a.mask) mask_in = a.mask[gi] != 0;
     if (mode != MODE_OBSERVE) {
       const uint4* ndp = reinterpret_cast<const uint4*>(a.next_deck + gi * NEXT_DECK_BYTES);

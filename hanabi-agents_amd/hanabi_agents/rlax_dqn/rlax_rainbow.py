@@ -330,6 +330,27 @@ class DQNAgent:
         return ops.policy_act(x, legal.to(torch.int8).contiguous(), self.atoms[0].contiguous(), epsilon,
                               self.params.seed + 0x9E3779B9, self._draws, self.first_game_id)
 
+    @torch.no_grad()
+    def q_for_step(self, observations, explore=True):
+        """explore() / exploit() split in two for drivers that fuse the epsilon-greedy selection into the env step
+        (HanabiEnv.step_select): runs the network and returns (q [N, A] fp32, epsilon, seed, draw, first_game_id) — exactly what
+        hb_policy_select would have been given — or None when this agent has no MFMA actor (then call explore())."""
+        if not self._fused:
+            return None
+        obs, legal, _ = self._unpack(observations)
+        fl = self._fused_learner() if self.actor_lag else self._fl
+        if fl is None or fl.actor is None or obs.dtype not in (torch.int8, torch.int32) or not self.use_mfma_actor:
+            return None
+        if self.params.resample_noise:
+            return None
+        wset = fl.acting_set()
+        self._draws += 1
+        if self._support0 is None:
+            self._support0 = self.atoms[0].contiguous()
+        q = fl.actor.q_values(obs.contiguous(), self._support0, s=wset)
+        eps = float(self.params.epsilon(self.train_step)) if explore else 0.0
+        return q, eps, self.params.seed + 0x9E3779B9, self._draws, self.first_game_id
+
     # ---- acting (rlax_rainbow.py:277-290) ---------------------------------------------------------------
     @torch.no_grad()
     def exploit(self, observations):

@@ -90,6 +90,7 @@ SIGNATURES = {
     "hb_env_step": (C.c_int, [_P] + [_P] * 8 + [_P]),
     "hb_env_observe_packed": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "hb_env_step_packed": (C.c_int, [_P] + [_P] * 9 + [_P]),
+    "hb_env_step_select_packed": (C.c_int, [_P, _P, _P, C.c_float, _U64, _U64, _I64, _P] + [_P] * 8 + [_P]),
     "hb_obs_pack": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "hb_obs_unpack": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "hb_env_illegal_count": (C.c_int, [_P, C.POINTER(_I64)]),

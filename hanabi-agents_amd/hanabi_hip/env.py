@@ -142,6 +142,24 @@ class HanabiEnv:
                                    K.dptr(self.score), K.current_stream()))
         return self._obs, self.legal, self.reward, self.terminal
 
+    def step_select(self, q, epsilon, seed, draw, first_game_id=0, actions_out=None):
+        """step() with the acting agent's epsilon-greedy selection fused into the env kernel (hb_env_step_select_packed):
+        game g plays the move hb_policy_select would pick from q[g] (fp32 [N, A]) and this env's current legal mask, with the
+        same Philox draws. Returns (actions, obs_bits, legal, reward, terminal); packed envs only."""
+        if not self.packed:
+            raise ValueError("step_select needs a packed env (HanabiEnv(packed=True))")
+        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape == (self.n, self.num_actions)
+        if actions_out is None:
+            actions_out = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        assert actions_out.dtype == torch.int32 and actions_out.is_contiguous() and actions_out.shape == (self.n,)
+        K.check(self.L.hb_env_step_select_packed(self.h, K.dptr(q), K.dptr(self.legal), float(epsilon), int(seed), int(draw),
+                                                 int(first_game_id), K.dptr(actions_out), K.dptr(self.obs_bits), None,
+                                                 K.dptr(self.legal), K.dptr(self.reward), K.dptr(self.terminal),
+                                                 K.dptr(self.agent_reward), K.dptr(self.agent_step_type), K.dptr(self.score),
+                                                 K.current_stream()))
+        self._obs_stale = True
+        return actions_out, self.obs_bits, self.legal, self.reward, self.terminal
+
     def random_legal_actions(self, seed, draw, out=None):
         """Uniform-random legal move per game (bench / tests policy)."""
         if out is None:

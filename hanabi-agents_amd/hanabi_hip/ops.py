@@ -92,6 +92,25 @@ class ActorMFMA:
                 self._jobs[key] = jobs
         K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))   # both layers in one launch
 
+    def q_values(self, obs, support, s=0):
+        """The two GEMMs of a policy call without the selection: q [N, A] fp32 (persistent buffer). For callers that fuse the
+        selection into their next kernel (HanabiEnv.step_select)."""
+        n = obs.shape[0]
+        packed = obs.dtype == torch.int32
+        assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
+                                        (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
+        if self.h is None or self.h.shape[0] != n:
+            self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
+            self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
+            self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
+        w1p, b1p, w2p, b2p = self._set_ptrs[s]
+        L, st = K.lib(), K.current_stream()
+        hidden = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden
+        K.check(hidden(obs.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p, self.hidden, self.h.data_ptr(), st))
+        K.check(L.hb_actor_q(self.h.data_ptr(), n, self.hidden, w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,
+                             self.q.data_ptr(), st))
+        return self.q
+
     def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0, s=0):
         n = obs.shape[0]
         packed = obs.dtype == torch.int32

@@ -24,13 +24,15 @@ from . import _capi as K
 
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
-                 learner_stream=True, learner_priority=-1, stream_per_agent=None):
+                 learner_stream=True, learner_priority=-1, stream_per_agent=None, fuse_select=True):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
         self.updates_per_step = int(updates_per_step)
         self.t = 0
         self.last_actions = [torch.zeros(env.n, dtype=torch.int32, device=env.device) for _ in agents]
+        self._act_buf = [torch.zeros(env.n, dtype=torch.int32, device=env.device) for _ in agents]
+        self.fuse_select = bool(fuse_select) and getattr(env, "packed", False) and env.device.type == "cuda"
         self.min_replay = min_replay
         self.train_seats = set(range(env.players)) if train_seats is None else set(train_seats)
         if overlap_allreduce is None:  # only worth the reordering when there is a collective to hide
@@ -94,9 +96,16 @@ class SelfPlaySession:
             agent.add_experience(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
         else:
             agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
-        actions = agent.explore(observations) if explore else agent.exploit(observations)
+        sel = agent.q_for_step(observations, explore) if (self.fuse_select and hasattr(agent, "q_for_step")) else None
+        if sel is not None:
+            # the network's q values go straight into the env kernel, which picks each game's move by the agent's own rule and
+            # draws (identical actions) and applies it: no selection launch, no round trip of the actions
+            actions = self._act_buf[seat]
+            env.step_select(sel[0], sel[1], sel[2], sel[3], sel[4], actions_out=actions)
+        else:
+            actions = agent.explore(observations) if explore else agent.exploit(observations)
+            env.step(actions)
         self.last_actions[seat] = actions
-        env.step(actions)
         acted = None
         if main is not None:
             # The policy has read the weights: the learner may overwrite them from here on. Recorded AFTER the env step:

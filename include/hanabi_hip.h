@@ -143,6 +143,15 @@ int hb_env_observe_packed(hb_env* env, uint32_t* obs_bits_dev, int8_t* obs_dev, 
 int hb_env_step_packed(hb_env* env, const int32_t* actions_dev, uint32_t* obs_bits_dev, int8_t* obs_dev, int8_t* legal_dev,
                        float* reward_dev, int8_t* terminal_dev, float* agent_reward_dev, int8_t* agent_step_type_dev,
                        int8_t* score_dev, void* stream);
+
+/* hb_env_step_packed with the acting agent's epsilon-greedy selection (DQNPolicy.policy's last step, rlax_rainbow.py:113-122)
+ * fused into the env kernel: game g's move is chosen from q_dev[g, :] (fp32 [N, A], 16-byte aligned) and sel_legal_dev[g, :]
+ * (int8 [N, A]: the previous step's legal output; it may be the same buffer as legal_dev) by the rule and Philox draws of
+ * hb_policy_select — identical actions — written to actions_out_dev[g] and applied. At most 64 actions.                    */
+int hb_env_step_select_packed(hb_env* env, const float* q_dev, const int8_t* sel_legal_dev, float epsilon, uint64_t seed,
+                              uint64_t draw, int64_t first_game_id, int32_t* actions_out_dev, uint32_t* obs_bits_dev,
+                              int8_t* obs_dev, int8_t* legal_dev, float* reward_dev, int8_t* terminal_dev,
+                              float* agent_reward_dev, int8_t* agent_step_type_dev, int8_t* score_dev, void* stream);
 /* int8 0/1 rows [rows, obs_len] <-> packed rows [rows, ceil(obs_len / 32)] u32 (any nonzero byte packs to 1).        */
 int hb_obs_pack(const int8_t* obs_dev, uint32_t* bits_dev, int64_t rows, int32_t obs_len, void* stream);
 int hb_obs_unpack(const uint32_t* bits_dev, int8_t* obs_dev, int64_t rows, int32_t obs_len, void* stream);

@@ -271,3 +271,39 @@ def test_arbitrary_uids_all_variants(game, players):
             env.step(torch.as_tensor(act).cuda())
             _assert_same(env, orc, orc.step(act), f"{game}/{players}p flags {extra} step {t}")
         assert env.illegal_count() == orc.illegal_count() > 0
+
+
+@pytest.mark.parametrize("game,players,n", [("Hanabi-Full", 2, 3000), ("Hanabi-Full", 5, 700), ("Hanabi-Small", 3, 500),
+                                            ("Hanabi-Very-Small", 2, 130)])
+def test_selection_fused_into_the_env_step_equals_select_then_step(game, players, n):
+    """hb_env_step_select_packed (each game's lane picks its move from q and the legal mask by hb_policy_select's rule and
+    draws, then applies it) against hb_policy_select followed by hb_env_step_packed: same actions, and the same state rows,
+    observations, legal masks, rewards and step types after every one of 60 steps (greedy and exploring, q with ties)."""
+    import torch
+
+    import hanabi_hip
+    from hanabi_hip import _capi as K
+
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    mk = lambda: hanabi_hip.HanabiEnv(config=hanabi_hip.make_config(game, players, flags), n_games=n, seed=21, first_game_id=777,
+                                      packed=True)
+    a, b = mk(), mk()
+    A = a.num_actions
+    g = torch.Generator(device="cuda").manual_seed(3)
+    L = K.lib()
+    for t in range(60):
+        q = torch.randn(n, A, device="cuda", generator=g)
+        if t % 3 == 0:
+            q = torch.round(q * 2) / 2            # many exact ties between the best moves
+        eps = (0.0, 0.3, 1.0)[t % 3]
+        act_a = torch.empty(n, dtype=torch.int32, device="cuda")
+        K.check(L.hb_policy_select(K.dptr(q), K.dptr(a.legal), n, A, eps, 99, 1000 + t, 777, K.dptr(act_a), K.current_stream()))
+        a.step(act_a)
+        act_b = b.step_select(q, eps, 99, 1000 + t, 777)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(act_a, act_b), f"step {t}: {(act_a != act_b).sum().item()} actions differ"
+        assert torch.equal(a.export_state(), b.export_state()), f"step {t}: state rows differ"
+        for x, y in ((a.obs_bits, b.obs_bits), (a.legal, b.legal), (a.reward, b.reward), (a.agent_reward, b.agent_reward),
+                     (a.agent_step_type, b.agent_step_type), (a.terminal, b.terminal)):
+            assert torch.equal(x, y)
+    assert a.illegal_count() == 0 and b.illegal_count() == 0 and a.stats() == b.stats()

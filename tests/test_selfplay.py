@@ -124,3 +124,43 @@ def test_learner_stream_gives_identical_training(dtype, graphs):
     assert torch.equal(st_a, st_b)
     for x, y in zip(w_a, w_b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lag", [0, 1])
+def test_selection_fused_into_the_env_step_gives_identical_training(lag):
+    """SelfPlaySession(fuse_select=True) (the env kernel picks the moves from the agent's q values) against the agent's own
+    explore() + env.step(): same actions every step, identical weights, replay rings, sum trees and env rows at the end."""
+    import torch
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    def run(fuse):
+        torch.manual_seed(0)
+        flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+        env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=512, seed=5, packed=True)
+        params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=8192, mask_terminal=True, target_update_period=7,
+                                   compute_dtype="bfloat16", packed_obs=True, layers=[256], actor_lag=lag, learning_rate=0.01)
+        agents = [DQNAgent(ObservationSpec((512, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
+                  for s in (1, 2)]
+        sess = SelfPlaySession(env, agents, fuse_select=fuse)
+        assert sess.fuse_select == fuse
+        acts = []
+        for _ in range(30):
+            sess.step()
+            acts.append(sess.last_actions[(sess.t - 1) % 2].clone())
+        sess.flush()
+        torch.cuda.synchronize()
+        out = [env.export_state(), env.obs_bits.clone()]
+        for a in agents:
+            out += [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]), a.experience.sum_tree.nodes(),
+                    a.experience._obs_t_buf.clone(), a.experience._act_tm1_buf.clone()]
+        return acts, out
+
+    (acts_a, out_a), (acts_b, out_b) = run(False), run(True)
+    for k, (x, y) in enumerate(zip(acts_a, acts_b)):
+        assert torch.equal(x, y), f"actions differ at step {k}"
+    for k, (x, y) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(x, y), f"item {k} differs"
