@@ -594,6 +594,182 @@ __global__ __launch_bounds__(NT) void gemm_v6(const Args a) {
   STAMP(63);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// variant 7: FOUR wavefronts per workgroup (one per SIMD), each owning a 128 x 128 quarter of the 256 x 256 tile: 256
+// accumulator registers (AGPRs) per lane. Per K step a wavefront reads (128 + 128) x 64 bf16 of fragments for 128 MFMAs,
+// i.e. 1.5x the FLOPs per LDS byte of the 128 x 64 wave tile of variants 0-6 (whose LDS reads, 197 KB per K step per
+// workgroup, take about as long as its MFMAs). Operands go global -> LDS directly (variant 1's loader, 16 glds per lane per
+// K step); the fragments of the next 32-wide K slice are requested before the current slice multiplies.
+constexpr int NT7 = 256;
+__device__ __forceinline__ void stage_tile7(const Args& a, unsigned char* base, int kt, int wave, int lane, long long row0, int col0) {
+  const int lr = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 64 * wave + 8 * i + lr;
+    const int c = pc ^ ((r >> 1) & 7);
+    long long row = row0 + r;
+    if (row >= a.m) row = a.m - 1;
+    unsigned char* dst = base + (64 * wave + 8 * i) * ROWB;
+    glds16(a.x + row * a.k + kt * BK + c * 8, dst);
+    glds16(a.wt + static_cast<long long>(col0 + r) * a.k + kt * BK + c * 8, dst + OPB);
+  }
+}
+
+template <bool STAMPS>
+__global__ __launch_bounds__(NT7) void gemm_v7(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k / BK;
+  STAMP(0);
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = OPB + (wc * 128 + (lane & 15)) * ROWB;
+  stage_tile7(a, lds, 0, wave, lane, row0, col0);
+  STAMP(1);
+  for (int kt = 0; kt < kt_n; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(2 + 4 * kt);
+    if (kt + 1 < kt_n) stage_tile7(a, lds + ((kt + 1) & 1) * STAGE, kt + 1, wave, lane, row0, col0);
+    STAMP(3 + 4 * kt);
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    bf16x8 wf[2][8], xf[2][8];
+    {
+      const int ch = ((0 * 4 + fq) ^ fsw) << 4;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) wf[0][n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xf[0][m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk == 0) {
+        const int ch = ((1 * 4 + fq) ^ fsw) << 4;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) wf[1][n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xf[1][m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+      }
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][n], xf[kk][m], acc[n][m], 0, 0, 0);
+    }
+    STAMP(4 + 4 * kt);
+  }
+  __syncthreads();
+  // epilogue: acc[n][m][j] = out[row wr*128 + 16 m + (lane & 15)][col wc*128 + 16 n + 4 (lane >> 4) + j]
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const int cl = wc * 128 + n * 16 + fq * 4;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int rl = wr * 128 + m * 16 + (lane & 15);
+      *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) =
+          make_uint2(pack_bf16(acc[n][m][0], acc[n][m][1]), pack_bf16(acc[n][m][2], acc[n][m][3]));
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    const int id = tid + NT7 * i, r = id >> 5, ch = id & 31;
+    if (row0 + r < a.m)
+      *reinterpret_cast<uint4*>(a.out + (row0 + r) * a.n + col0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + r * OUT_LD + ch * 16);
+  }
+  STAMP(63);
+}
+
+// variant 8: variant 7 with the main loop's issue order pinned (sched_group_barrier): see the comment in the loop
+template <bool STAMPS>
+__global__ __launch_bounds__(NT7) void gemm_v8(const Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long long row0 = static_cast<long long>(blockIdx.x) * BM;
+  const int col0 = static_cast<int>(blockIdx.y) * BN;
+  const int kt_n = a.k / BK;
+  STAMP(0);
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = (lane & 15) >> 1, fq = lane >> 4;
+  const int x_off = (wr * 128 + (lane & 15)) * ROWB;
+  const int w_off = OPB + (wc * 128 + (lane & 15)) * ROWB;
+  stage_tile7(a, lds, 0, wave, lane, row0, col0);
+  STAMP(1);
+  for (int kt = 0; kt < kt_n; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(2 + 4 * kt);
+    // (unconditional: the last iteration re-stages the last tile into the idle buffer, so the loop body stays one basic block
+    // and the schedule below applies to all of it)
+    stage_tile7(a, lds + ((kt + 1) & 1) * STAGE, kt + 1 < kt_n ? kt + 1 : kt_n - 1, wave, lane, row0, col0);
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+    bf16x8 wf[2][8], xf[2][8];
+    {
+      const int ch = ((0 * 4 + fq) ^ fsw) << 4;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) wf[0][n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xf[0][m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+    }
+    {
+      const int ch = ((1 * 4 + fq) ^ fsw) << 4;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) wf[1][n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * ROWB + ch);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xf[1][m] = *reinterpret_cast<const bf16x8*>(cur + x_off + m * 16 * ROWB + ch);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][n], xf[kk][m], acc[n][m], 0, 0, 0);
+    // schedule: the 16 direct-to-LDS loads of the next tile, the 16 fragment reads of the first K slice, then the second
+    // slice's 16 reads spread one per 4 MFMAs of the first slice, then the second slice's 64 MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+    STAMP(4 + 4 * kt);
+  }
+  __syncthreads();
+  // epilogue: acc[n][m][j] = out[row wr*128 + 16 m + (lane & 15)][col wc*128 + 16 n + 4 (lane >> 4) + j]
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const int cl = wc * 128 + n * 16 + fq * 4;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int rl = wr * 128 + m * 16 + (lane & 15);
+      *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) =
+          make_uint2(pack_bf16(acc[n][m][0], acc[n][m][1]), pack_bf16(acc[n][m][2], acc[n][m][3]));
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    const int id = tid + NT7 * i, r = id >> 5, ch = id & 31;
+    if (row0 + r < a.m)
+      *reinterpret_cast<uint4*>(a.out + (row0 + r) * a.n + col0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + r * OUT_LD + ch * 16);
+  }
+  STAMP(63);
+}
+
 }  // namespace
 
 extern "C" int probe_gemm(int variant, int stamped, const void* x, long long m, int k, const void* wt, int n, void* out,
@@ -613,6 +789,14 @@ extern "C" int probe_gemm(int variant, int stamped, const void* x, long long m, 
   else if (variant == 4) LAUNCH(gemm_v4);
   else if (variant == 5) LAUNCH(gemm_v5);
   else if (variant == 6) LAUNCH(gemm_v6);
+  else if (variant == 7) {
+    if (stamped) hipLaunchKernelGGL((gemm_v7<true>), grid, dim3(NT7), 0, s, a);
+    else hipLaunchKernelGGL((gemm_v7<false>), grid, dim3(NT7), 0, s, a);
+  }
+  else if (variant == 8) {
+    if (stamped) hipLaunchKernelGGL((gemm_v8<true>), grid, dim3(NT7), 0, s, a);
+    else hipLaunchKernelGGL((gemm_v8<false>), grid, dim3(NT7), 0, s, a);
+  }
   else return -2;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
