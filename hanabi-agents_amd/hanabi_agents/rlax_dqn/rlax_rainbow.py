@@ -202,8 +202,14 @@ class DQNAgent:
         if self.actor_lag and not (self._fused and use_fused_learner and params.use_priority and len(params.layers) == 1):
             raise ValueError("actor_lag=1 needs the HIP fused learner (GPU, C51 head, one hidden layer) with prioritized replay")
         self._support0 = None       # atoms[0], contiguous (the support every action shares)
-        self._pending_fills = []    # actor_lag: (start, rows) of inserts whose sum-tree leaves the NEXT update_begin() sets
-        self.gathered_ev = None     # actor_lag: recorded when an update has finished reading the replay rings
+        # split update (always with actor_lag; set_split_update() for synchronous agents driven with a learner stream): the
+        # sum tree is written only on the stream the updates run on, sampling + gather is its own launch followed by
+        # `gathered_ev`, and the priority write-back runs after `weights_ev` — so the acting stream may insert as soon as the
+        # rings have been read and act as soon as Adam has written the weights, instead of waiting for the whole update
+        self.split_update = bool(self.actor_lag)
+        self._pending_fills = []    # (start, rows) of inserts whose sum-tree leaves the NEXT update_begin() sets
+        self.gathered_ev = None     # recorded when an update has finished reading the replay rings
+        self.weights_ev = None      # recorded when an update's optimizer step is done (before its priority write-back)
 
     @property
     def last_loss(self):
@@ -292,6 +298,12 @@ class DQNAgent:
         self._last_q = q
         return actions
 
+    def _wait_for_weights(self):
+        """split update of a synchronous agent: the policy call waits (on the calling stream) for the last optimizer step's
+        event — not for the priority write-back that follows it on the learner stream."""
+        if self.split_update and not self.actor_lag and self.weights_ev is not None:
+            self.weights_ev.wait()
+
     def _act_fused(self, obs, legal, epsilon):
         """Actor on the GPU: int8 obs -> GEMM dtype, two bias-fused MFMA GEMMs, then ONE kernel for
         softmax-expectation + legal mask + epsilon-greedy sample (hb_policy_act)."""
@@ -300,6 +312,7 @@ class DQNAgent:
         if self.params.resample_noise:
             self.online.resample()
             self._eff_cache = None
+        self._wait_for_weights()
         eff = self._effective_weights()
         fl = self._fused_learner() if self.actor_lag else self._fl
         if fl is not None and fl.actor is not None and obs.dtype in (torch.int8, torch.int32) and self.use_mfma_actor:
@@ -343,6 +356,7 @@ class DQNAgent:
             return None
         if self.params.resample_noise:
             return None
+        self._wait_for_weights()
         wset = fl.acting_set()
         self._draws += 1
         if self._support0 is None:
@@ -409,10 +423,10 @@ class DQNAgent:
             buf, n = self.experience, obs.shape[0]
             start = buf.oldest_entry
             if self.params.use_priority:  # new leaves enter at max priority (priority_buffer.py:29-32)
-                if self.actor_lag:
-                    # asynchronous actor: the sum tree is written ONLY on the stream the updates run on. The leaves of these
-                    # rows are set by the next update_begin(), i.e. after the priority write-back of the update in flight and
-                    # before the next sampling: the same order of tree writes as with actor_lag=0.
+                if self.split_update:
+                    # the sum tree is written ONLY on the stream the updates run on. The leaves of these rows are set by the
+                    # next update_begin(), i.e. after the priority write-back of the update in flight and before the next
+                    # sampling: the same order of tree writes as in the plain sequential form.
                     self._pending_fills.append((start, n))
                 else:
                     buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
@@ -448,15 +462,28 @@ class DQNAgent:
     # replay insert, policy and env step between the two calls, so the ~3.4 MB gradient exchange over xGMI hides
     # behind ~0.2 ms of independent work. With one rank the pair is exactly update() — and, under HIP graphs, the whole
     # update (Adam included) is one graph launched by update_begin(): do not let anything read the weights between the two.
+    def set_split_update(self, on=True):
+        """Turn the split form of update() on (see __init__) for a synchronous agent; returns whether it is in effect. Needs
+        the fused learner with prioritized replay; agents with actor_lag always use it. Results do not depend on it."""
+        on = bool(on) or bool(self.actor_lag)
+        if on and not (self._fused and self.use_fused_learner and self.params.use_priority and len(self.params.layers) == 1
+                       and not self.params.resample_noise and self._graphs_enabled()):
+            return False
+        if on != self.split_update:
+            assert self._pending is None and not self._pending_fills
+            self.split_update = on
+            self._graph1 = self._graph2 = None   # the captured update has the other shape: capture again at the next update
+        return on
+
     def apply_pending_fills(self):
-        """actor_lag: set the sum-tree leaves of the rows inserted since the last update (on the CURRENT stream, which must be
+        """split update: set the sum-tree leaves of the rows inserted since the last update (on the CURRENT stream, which must be
         the one the updates run on)."""
         for start, n in self._pending_fills:
             self.experience.sum_tree.fill_range_dev(start, n, self.experience._max_priority)
         self._pending_fills.clear()
 
     def _pre_gather(self):
-        """actor_lag: sampling + replay gather as their own launch in front of the (captured) rest of the update, followed by
+        """split update: sampling + replay gather as their own launch in front of the (captured) rest of the update, followed by
         an event: from there on the update no longer reads the rings, and the acting stream may overwrite their oldest rows."""
         fl = self._fused_learner()
         fl.sample_and_gather(self.params.seed + 0x51ED270B + 0x9E3779B1 * self.first_game_id)
@@ -468,7 +495,7 @@ class DQNAgent:
 
     def update_begin(self):
         assert self._pending is None, "update_finish() of the previous update has not been called"
-        if self.actor_lag:
+        if self.split_update:
             self.apply_pending_fills()
         self.experience.sync_size()
         beta = float(self.params.beta_is(self.train_step))
@@ -478,12 +505,12 @@ class DQNAgent:
         if self._graphs_enabled():
             if self._graph1 is None:
                 self._capture_update_graphs()
-            if self.actor_lag:
+            if self.split_update:
                 self._pre_gather()
             self._graph1.replay()
             part2_args = None
         else:
-            if self.actor_lag:
+            if self.split_update:
                 self._pre_gather()
             self.last_loss, indices, new_prios = self._update_part1()
             part2_args = (indices, new_prios)
@@ -498,11 +525,14 @@ class DQNAgent:
         if part2_args is None:
             if self._graph2 is not None:  # (single rank: the second half was captured into the first graph)
                 self._graph2.replay()
+            part2_args = (self._g_idx, self._g_prios)
         else:
             self._update_part2(*part2_args)
         self._eff_cache = None
         if self._fl is not None:
             self._fl.weights_updated()  # Adam rewrote the effective weights: the actor's copies follow (lazily, or now: actor_lag)
+        if self.split_update:
+            self._after_optimizer_step(*part2_args)
         if self.train_step % self.params.target_update_period == 0:  # after the step, including step 0 (C-10)
             self._sync_target()
         self.train_step += 1
@@ -605,7 +635,7 @@ class DQNAgent:
                 self.target.resample()
                 fl.refresh_effective()
                 fl.refresh_target()
-            if self.actor_lag:
+            if self.split_update:
                 indices, prios, gathered = fl._idx, fl._prob, True   # filled by _pre_gather(), outside the captured part
             elif self.params.use_priority and "_sample_indices" not in self.__dict__:
                 # PER: tree descent and replay gather in one launch (same draws as _sample_indices below)
@@ -634,21 +664,34 @@ class DQNAgent:
         loss.backward()  # every p.grad is a view into _flat_grad: gradients accumulate in place
         return loss.detach(), indices, new_prios
 
+    def _after_optimizer_step(self, indices, new_prios):
+        """split update: the weights are final here — mark it for the acting stream, THEN write the priorities back (outside
+        the captured graph: the acting stream does not wait for this launch)."""
+        if self.weights_ev is None:
+            from hanabi_hip import _capi as K
+
+            self.weights_ev = K.Event()
+        self.weights_ev.record()
+        if self.params.use_priority:
+            self.experience.update_priorities_dev(indices, new_prios)
+
     def _update_part2(self, indices, new_prios):
         if self._fl is not None:
             self._fl.part2()
         else:
             self.optimizer.step()
-        if self.params.use_priority:
+        if self.params.use_priority and not self.split_update:
             # (running this on a forked graph branch beside Adam was measured slower: 0.216 vs 0.190 ms per update)
             self.experience.update_priorities_dev(indices, new_prios)
 
     def _update_eager(self):
-        if self.actor_lag:
+        if self.split_update:
             self._pre_gather()
         self.last_loss, indices, new_prios = self._update_part1()
         self._finish_allreduce(self._allreduce_gradients(async_op=False))
         self._update_part2(indices, new_prios)
+        if self.split_update and self.params.use_priority:
+            self.experience.update_priorities_dev(indices, new_prios)
 
     def _graphs_enabled(self):
         return self.use_graphs and self.device.type == "cuda"

@@ -30,4 +30,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learner -- pytho
 python3 scripts/gemm_probe.py 0,1,3 > $O/gemm_probe.log 2>&1
 python3 scripts/coresidency_probe.py > $O/coresidency_probe.log 2>&1
 python3 scripts/bwd_probe.py > $O/bwd_probe.log 2>&1
+python3 scripts/gemm_probe.py 0,7,8 > $O/gemm_probe_wave128.log 2>&1
+# kernel timelines of the synchronous loop and of the asynchronous-actor loop (per queue: busy share, in-loop kernel durations)
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_sync -- python3 bench.py --steps 300 --warmup 40 --no-cpu-baseline --no-async-variant > /dev/null 2>> $O/err.log
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_async -- python3 bench.py --steps 300 --warmup 40 --no-cpu-baseline --actor-lag 1 > /dev/null 2>> $O/err.log
+python3 scripts/timeline.py $O/trace_sync > $O/timeline_sync.txt
+python3 scripts/timeline.py $O/trace_async > $O/timeline_async.txt
+rm -rf $O/trace_sync $O/trace_async
+# the driver's own invocation (20 timed steps)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_settings.json 2>> $O/err.log
 echo done
