@@ -98,6 +98,7 @@ class FusedLearner:
         self._gb2_pad = torch.zeros(self.Np, **f32)
         self._adam_tab = None
         self._idx = self._prob = None     # outputs of the fused sample + gather launch
+        self._sg_call = None              # cached argument list of that launch
         # Single rank: Adam reads the weight gradients straight from the (padded, GEMM-dtype) outputs of the two
         # backward GEMMs and the bias gradients from the column-sum outputs: no pack / convert launches. With data
         # parallelism the gradients are first packed into the flat fp32 all-reduce bucket above.
@@ -183,19 +184,27 @@ class FusedLearner:
     def sample_and_gather(self, seed):
         """Prioritized sampling (hb_per_sample_philox) and the gather into the GEMM operand as ONE launch. Returns the sampled
         indices and probabilities (persistent buffers); part1(..., gathered=True) then skips its own gather."""
-        a, L = self.agent, K.lib()
+        a = self.agent
         buf, B = a.experience, self.B
-        if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
+        rpi = buf.rows_per_insert
+        c = self._sg_call
+        if c is not None and c[0] == (rpi, buf._obs_t_buf.data_ptr()) and c[1] == seed:   # only the stream can differ from last time
+            K.check(c[2](*c[3], K.current_stream()))
+            return self._idx, self._prob
+        L = K.lib()
+        if a.params.n_step > 1 and (rpi is None or rpi < 1):
             raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         if self._idx is None:
             self._idx = torch.empty(B, dtype=torch.int64, device=a.device)
             self._prob = torch.empty(B, dtype=torch.float64, device=a.device)
-        K.check(L.hb_per_sample_gather(buf.sum_tree.h, int(seed), K.dptr(self.step), B, K.dptr(self._idx), K.dptr(self._prob),
-                                       K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
-                                       K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), self.L, 1 if buf.packed else 0,
-                                       K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew), K.dptr(self.term),
-                                       K.dptr(self.disc), int(a.params.n_step), float(a.params.discount), buf.capacity,
-                                       int(buf.rows_per_insert or 1), K.dptr(buf._size_wp), K.current_stream()))
+        args = (buf.sum_tree.h, int(seed), K.dptr(self.step), B, K.dptr(self._idx), K.dptr(self._prob),
+                K.dptr(buf._obs_tm1_buf), K.dptr(buf._obs_t_buf), K.dptr(buf._act_tm1_buf),
+                K.dptr(buf._rew_t_buf), K.dptr(buf._terminal_t_buf), self.L, 1 if buf.packed else 0,
+                K.dptr(self.x), _DT[self.cd], self.Kp, K.dptr(self.act), K.dptr(self.rew), K.dptr(self.term),
+                K.dptr(self.disc), int(a.params.n_step), float(a.params.discount), buf.capacity,
+                int(rpi or 1), K.dptr(buf._size_wp))
+        self._sg_call = ((rpi, buf._obs_t_buf.data_ptr()), seed, L.hb_per_sample_gather, args)   # (all operands are persistent buffers of this learner / ring)
+        K.check(L.hb_per_sample_gather(*args, K.current_stream()))
         return self._idx, self._prob
 
     def part1(self, indices, prios, gathered=False):

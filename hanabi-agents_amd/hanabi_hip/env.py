@@ -56,6 +56,7 @@ class HanabiEnv:
         self.agent_step_type = torch.zeros(self.n, dtype=torch.int8, device=dev)
         self.score = torch.zeros(self.n, dtype=torch.int8, device=dev)
         self._decks = None
+        self._sel_call = None   # step_select: cached argument addresses
         if games_per_wave is not None:
             self.set_games_per_wave(games_per_wave)
         if decks is not None:
@@ -148,15 +149,19 @@ class HanabiEnv:
         same Philox draws. Returns (actions, obs_bits, legal, reward, terminal); packed envs only."""
         if not self.packed:
             raise ValueError("step_select needs a packed env (HanabiEnv(packed=True))")
-        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape == (self.n, self.num_actions)
         if actions_out is None:
             actions_out = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        assert actions_out.dtype == torch.int32 and actions_out.is_contiguous() and actions_out.shape == (self.n,)
-        K.check(self.L.hb_env_step_select_packed(self.h, K.dptr(q), K.dptr(self.legal), float(epsilon), int(seed), int(draw),
-                                                 int(first_game_id), K.dptr(actions_out), K.dptr(self.obs_bits), None,
-                                                 K.dptr(self.legal), K.dptr(self.reward), K.dptr(self.terminal),
-                                                 K.dptr(self.agent_reward), K.dptr(self.agent_step_type), K.dptr(self.score),
-                                                 K.current_stream()))
+        c = self._sel_call
+        if c is None or c[0] != (q.data_ptr(), actions_out.data_ptr()):
+            assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape == (self.n, self.num_actions)
+            assert actions_out.dtype == torch.int32 and actions_out.is_contiguous() and actions_out.shape == (self.n,)
+            # (the env's own output buffers never move: their addresses are converted once)
+            c = self._sel_call = ((q.data_ptr(), actions_out.data_ptr()), self.legal.data_ptr(),
+                                  (self.obs_bits.data_ptr(), None, self.legal.data_ptr(), self.reward.data_ptr(),
+                                   self.terminal.data_ptr(), self.agent_reward.data_ptr(), self.agent_step_type.data_ptr(),
+                                   self.score.data_ptr()))
+        K.check(self.L.hb_env_step_select_packed(self.h, c[0][0], c[1], float(epsilon), int(seed), int(draw), int(first_game_id),
+                                                 c[0][1], *c[2], K.current_stream()))
         self._obs_stale = True
         return actions_out, self.obs_bits, self.legal, self.reward, self.terminal
 

@@ -46,6 +46,20 @@ def replay_insert(last_obs, obs, legal, actions, rewards, step_types, ring, star
                                      K.current_stream()))
 
 
+def replay_insert_call(last_obs, obs, legal, actions, rewards, step_types, ring):
+    """(launcher, fixed arguments, stream getter) of the replay_insert() call just made with these buffers: calling
+    `launcher(*fixed, start, stream())` repeats it for another ring position without re-validating or re-converting anything."""
+    n, obs_len = obs.shape[0], obs.shape[1] * obs.element_size()
+    fixed = (last_obs.data_ptr(), obs.data_ptr(), legal.data_ptr(), actions.data_ptr(), rewards.data_ptr(), step_types.data_ptr(),
+             ring._obs_tm1_buf.data_ptr(), ring._obs_t_buf.data_ptr(), ring._act_tm1_buf.data_ptr(), ring._lms_t_buf.data_ptr(),
+             ring._rew_t_buf.data_ptr(), ring._terminal_t_buf.data_ptr(), n, obs_len, legal.shape[1], ring.capacity)
+    fn = K.lib().hb_replay_insert
+
+    def launch(*a):
+        K.check(fn(*a))
+    return launch, fixed, K.current_stream
+
+
 class ActorMFMA:
     """The actor's forward pass on the hand-written MFMA kernels (csrc/actor.hip): packed (transposed) copies of
     the effective weights plus the scratch buffers; `pack` after every weight change, `act` per step."""
@@ -64,6 +78,7 @@ class ActorMFMA:
         self.w1t, self.b1, self.w2t, self.b2 = self.sets[0]
         self.h = self.q = self.actions = None
         self._jobs = {}
+        self._q_call = None   # q_values: cached argument addresses
         # True: selection inside the output-layer GEMM (hb_actor_q_select with ticket counters). Bit-identical actions; measured
         # r02: NOT faster (policy call 82 vs 75 us: the selecting workgroups hold their CU's LDS while they run a latency-bound
         # tail, which delays the GEMM's second round of workgroups), so the separate hb_policy_select launch stays the default
@@ -95,20 +110,25 @@ class ActorMFMA:
     def q_values(self, obs, support, s=0):
         """The two GEMMs of a policy call without the selection: q [N, A] fp32 (persistent buffer). For callers that fuse the
         selection into their next kernel (HanabiEnv.step_select)."""
-        n = obs.shape[0]
-        packed = obs.dtype == torch.int32
-        assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
-                                        (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
-        if self.h is None or self.h.shape[0] != n:
-            self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
-            self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
-            self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
+        c = self._q_call
+        if c is None or c[0] != obs.data_ptr() or self.h is None or c[4] != self.h.data_ptr() or c[6] != support.data_ptr():
+            # a new operand (or re-allocated scratch): validate once, then reuse the converted arguments
+            n = obs.shape[0]
+            packed = obs.dtype == torch.int32
+            assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
+                                            (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
+            if self.h is None or self.h.shape[0] != n:
+                self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
+                self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
+                self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
+            L = K.lib()
+            c = self._q_call = (obs.data_ptr(), n, L.hb_actor_hidden_packed if packed else L.hb_actor_hidden, L.hb_actor_q,
+                                self.h.data_ptr(), self.q.data_ptr(), support.data_ptr())
+        _, n, hidden, qfn, hp, qp, sp = c
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
-        L, st = K.lib(), K.current_stream()
-        hidden = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden
-        K.check(hidden(obs.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p, self.hidden, self.h.data_ptr(), st))
-        K.check(L.hb_actor_q(self.h.data_ptr(), n, self.hidden, w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,
-                             self.q.data_ptr(), st))
+        st = K.current_stream()
+        K.check(hidden(c[0], n, self.obs_len, w1p, self.k_pad, b1p, self.hidden, hp, st))
+        K.check(qfn(hp, n, self.hidden, w2p, b2p, sp, self.n_actions, self.n_atoms, qp, st))
         return self.q
 
     def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0, s=0):
