@@ -340,7 +340,7 @@ def main():
         if args.learner_cus > 0 and lstream:
             from hanabi_hip.streams import masked_stream
 
-            lstream = masked_stream(0, args.learner_cus, device)
+            lstream = lambda: masked_stream(0, args.learner_cus, device)   # (a factory: one masked stream per agent)
             main_stream = masked_stream(args.learner_cus, 256, device)
         session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_stream=lstream,
                                   learner_priority=args.learner_priority,

@@ -880,6 +880,8 @@ class DQNAgent:
     # run continues bit-for-bit (tests/test_checkpoint.py). Everything is a plain dict of tensors / numbers: it
     # loads with torch.load(weights_only=True).
     def checkpoint_state(self, include_replay=True):
+        if self._pending_fills:   # split update: leaves of rows inserted since the last update (the caller has joined the streams)
+            self.apply_pending_fills()
         sd = dict(format="hanabi-agents_amd/agent/1", params=repr(self.params), train_step=self.train_step,
                   draws=self._draws, first_game_id=self.first_game_id, seed=int(self.params.seed),
                   online={k: v.cpu() for k, v in self.online.state_dict().items()},

@@ -45,10 +45,14 @@ class SelfPlaySession:
         # env step (big GEMMs on the main stream, the ~30 small learner kernels on the side). Every dependency of the
         # sequential order is kept by events, so results are identical to running everything on one stream.
         self.learner_stream = None
+        self._stream_factory = None
         if learner_stream and env.device.type == "cuda" and len(set(map(id, agents))) == len(agents) and len(agents) > 1:
             # (a torch.cuda.Stream / ExternalStream may be passed in, e.g. one restricted to a CU subset: streams.py)
-            self.learner_stream = learner_stream if isinstance(learner_stream, torch.cuda.Stream) else torch.cuda.Stream(
-                device=env.device, priority=learner_priority)
+            # (also accepted: a callable returning a new stream each time it is called — one per agent with per-agent streams)
+            self._stream_factory = learner_stream if callable(learner_stream) and not isinstance(learner_stream, torch.cuda.Stream) else None
+            self.learner_stream = (self._stream_factory() if self._stream_factory else
+                                   learner_stream if isinstance(learner_stream, torch.cuda.Stream) else
+                                   torch.cuda.Stream(device=env.device, priority=learner_priority))
         self._main, self._main_raw = None, -1
         import torch.distributed as dist
 
@@ -155,6 +159,7 @@ class SelfPlaySession:
         ls = self._lstreams.get(id(agent))
         if ls is None:
             ls = self._lstreams[id(agent)] = (self.learner_stream if not self._lstreams else
+                                              self._stream_factory() if self._stream_factory else
                                               torch.cuda.Stream(device=self.env.device, priority=self.learner_stream.priority))
         return ls
 
