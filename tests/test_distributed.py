@@ -158,7 +158,7 @@ def test_rank_shards_use_disjoint_reproducible_decks():
     assert len({bytes(r[16:29].tobytes()) for r in whole}) == 64   # all decks differ
 
 
-def _gpu_worker(rank, world, port, out):
+def _gpu_worker(rank, world, port, out, lag=0):
     """Full self-play + fused learner (packed all-reduce bucket, HIP graphs around the collective, learner stream, MFMA
     actor) with two ranks sharing ONE GPU; gloo moves the CUDA gradient bucket (RCCL needs one GPU per rank)."""
     for p in (ROOT, os.path.join(ROOT, "hanabi-agents_amd")):
@@ -173,9 +173,10 @@ def _gpu_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     n = 128
     flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
-    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=n, seed=9, first_game_id=rank * n)
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=n, seed=9, first_game_id=rank * n,
+                               packed=bool(lag))
     params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=n * 8, layers=[256], compute_dtype="bfloat16",
-                               mask_terminal=True, target_update_period=5)
+                               mask_terminal=True, target_update_period=5, actor_lag=lag, packed_obs=bool(lag))
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=40 + s), device="cuda")
               for s in (0, 1)]
     for a in agents:
@@ -197,9 +198,12 @@ def _gpu_worker(rank, world, port, out):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_stay_in_lock_step(tmp_path):
+@pytest.mark.parametrize("lag", [0, 1])
+def test_two_ranks_on_one_gpu_stay_in_lock_step(tmp_path, lag):
+    """lag = 1: the asynchronous actor (double-buffered weights, split update, per-agent learner streams) under data
+    parallelism: the replicas still end bit-identical."""
     world, port = 2, _free_port()
-    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path), lag), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"g{i}.pt") for i in range(world)]
     assert r[0]["grad_steps"] == r[1]["grad_steps"] > 0 and r[0]["illegal"] == r[1]["illegal"] == 0
     assert not torch.equal(r[0]["rows"], r[1]["rows"])                     # different games on each rank (Philox by global id)
