@@ -26,6 +26,14 @@ Extra objects on the same JSON line:
   cpu_baseline  the CPU oracle (oracle/, a port: the reference's env is not in its tree) on the
                 host cores, bounded sample of the same workload, rank 0 only
 """
+# HIP maps its streams onto at most GPU_MAX_HW_QUEUES hardware queues (ROCm default 4). The step interleaves an acting stream, one
+# learner stream per agent and, data-parallel, RCCL's stream; which of them share a hardware queue changes the step time by up to
+# 3x (measured r02, one MI355X: multi-rank update path 0.47 ms per step with 4 queues, 0.17 ms with 2; single-rank path 0.144 ms
+# with either; 3 or 8 queues are pathological for one path or the other: profiles/r02/hw_queues.txt). Must be set before the HIP
+# runtime initialises; an explicit setting in the environment wins.
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import argparse
 import json
 import os
@@ -304,6 +312,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knob (one-GPU box): HB_BENCH_FORCE_COLLECTIVE=1 with --gpus 1 starts a ONE-rank RCCL group and routes every
+    # update through the multi-rank path (gradient bucket, graphs around the all-reduce): its cost without the wire time
+    force_coll = world == 1 and os.environ.get("HB_BENCH_FORCE_COLLECTIVE") == "1"
+    if force_coll:
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     import hanabi_hip
     from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
@@ -331,6 +345,7 @@ def main():
                            params._replace(seed=1234 + 17 * s), device=device) for s in range(args.players)]
         for a in agents:
             a.first_game_id = rank * n  # keys the exploration RNG by global game id
+            a.force_collective = force_coll
         if world > 1:  # identical initial weights on every rank (data parallel)
             for a in agents:
                 for t in list(a.online.parameters()) + list(a.online.buffers()):
@@ -521,10 +536,13 @@ def main():
             note("cpu_baseline_learner done")
         line["cpu_baseline_sum_tree"] = sum_tree_baseline(device)
         note("cpu_baseline_sum_tree done")
+    if force_coll:
+        line["config"]["parallelism"] += " [HB_BENCH_FORCE_COLLECTIVE: one-rank RCCL group, multi-rank update path]"
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 
@@ -544,6 +562,7 @@ def async_variant(args, rank, world, device, n):
                        device=device) for s in range(args.players)]
     for a in agents:
         a.first_game_id = rank * n
+        a.force_collective = world == 1 and os.environ.get("HB_BENCH_FORCE_COLLECTIVE") == "1"
     if world > 1:
         for a in agents:
             for t in list(a.online.parameters()) + list(a.online.buffers()):

@@ -212,7 +212,7 @@ class FusedLearner:
         a, L = self.agent, K.lib()
         buf, B = a.experience, self.B
         if self.direct is None:
-            self.direct = a._dp_world() == 1
+            self.direct = not a._collective()
         if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
             raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         s = K.current_stream()

@@ -201,6 +201,8 @@ class DQNAgent:
         self.actor_lag = int(params.actor_lag)
         if self.actor_lag and not (self._fused and use_fused_learner and params.use_priority and len(params.layers) == 1):
             raise ValueError("actor_lag=1 needs the HIP fused learner (GPU, C51 head, one hidden layer) with prioritized replay")
+        self.force_collective = False   # see _collective()
+        self._ar_avg = None             # gradient all-reduce averages inside the collective (RCCL) or sums (gloo: divided after)
         self._support0 = None       # atoms[0], contiguous (the support every action shares)
         self._dense_call = None     # add_experience_dense: (input addresses, rows, launcher, fixed arguments, stream getter)
         # split update (always with actor_lag; set_split_update() for synchronous agents driven with a learner stream): the
@@ -795,7 +797,7 @@ class DQNAgent:
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog polling its events in a
         # data-parallel run) must not invalidate the capture
-        if self._dp_world() == 1:
+        if not self._collective():
             # no collective between the halves: one graph, one launch (graph2 stays empty-handed: see update_finish)
             with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
                 self.last_loss, self._g_idx, self._g_prios = self._update_part1()
@@ -816,6 +818,18 @@ class DQNAgent:
             return 1
         return dist.get_world_size(self.process_group)
 
+    def _collective(self):
+        """Does an update go through the all-reduce path (flat gradient bucket, two captured halves around the collective)?
+        More than one rank — or `force_collective` with an initialised process group of ONE rank, which runs exactly the
+        multi-rank code path (RCCL included) on a one-GPU box (tests/test_distributed.py)."""
+        if self._dp_world() > 1:
+            return True
+        if self.force_collective and self.process_group is not False:
+            import torch.distributed as dist
+
+            return dist.is_available() and dist.is_initialized()
+        return False
+
     def _note_local_is_max(self, prios):
         """global_is_max: remember this rank's max_i (1/P_i)^beta (the normaliser its loss used) for the rescale below."""
         if self.params.global_is_max and self._dp_world() > 1:
@@ -834,11 +848,11 @@ class DQNAgent:
         over the global batch, exactly."""
         import torch.distributed as dist
 
-        world = self._dp_world()
-        if self._fl is not None and self._fl.direct is not None and self._fl.direct != (world == 1):
+        coll = self._collective()
+        if self._fl is not None and self._fl.direct is not None and self._fl.direct != (not coll):
             raise RuntimeError("the process group changed after the FusedLearner was built: its gradient routing "
                                "(direct GEMM outputs vs packed all-reduce bucket) no longer matches the world size")
-        if world == 1:
+        if not coll:
             return None
         flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
         if self.params.global_is_max:
@@ -850,19 +864,23 @@ class DQNAgent:
                 self._fl.w_is.mul_(scale)   # last_loss = mean(td * w_IS) reports the globally normalised weights
             elif self._last_loss is not None:
                 self._last_loss = self._last_loss * scale[0]
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        if self._ar_avg is None:   # RCCL averages inside the collective (ncclAvg); gloo has no AVG: sum, then divide
+            self._ar_avg = dist.get_backend(self.process_group) == "nccl"
+        work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._ar_avg else dist.ReduceOp.SUM, group=self.process_group,
+                               async_op=True)
         if not async_op:
             work.wait()
         return work
 
     def _finish_allreduce(self, work):
-        world = self._dp_world()
-        if world == 1:
+        if not self._collective():
             return
+        world = self._dp_world()
         if work is not None:
             work.wait()  # orders the current stream after the collective; does not block the host on NCCL/RCCL
-        flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
-        flat /= world
+        if not self._ar_avg:
+            flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
+            flat /= world
 
     # ---- misc --------------------------------------------------------------------------------------------
     def __repr__(self):
