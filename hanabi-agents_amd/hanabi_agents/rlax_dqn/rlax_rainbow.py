@@ -202,6 +202,7 @@ class DQNAgent:
         if self.actor_lag and not (self._fused and use_fused_learner and params.use_priority and len(params.layers) == 1):
             raise ValueError("actor_lag=1 needs the HIP fused learner (GPU, C51 head, one hidden layer) with prioritized replay")
         self.force_collective = False   # see _collective()
+        self._last_coll = False
         self._ar_avg = None             # gradient all-reduce averages inside the collective (RCCL) or sums (gloo: divided after)
         self._support0 = None       # atoms[0], contiguous (the support every action shares)
         self._dense_call = None     # add_experience_dense: (input addresses, rows, launcher, fixed arguments, stream getter)
@@ -848,7 +849,7 @@ class DQNAgent:
         over the global batch, exactly."""
         import torch.distributed as dist
 
-        coll = self._collective()
+        coll = self._last_coll = self._collective()   # (_finish_allreduce of the same update reuses the answer)
         if self._fl is not None and self._fl.direct is not None and self._fl.direct != (not coll):
             raise RuntimeError("the process group changed after the FusedLearner was built: its gradient routing "
                                "(direct GEMM outputs vs packed all-reduce bucket) no longer matches the world size")
@@ -873,14 +874,13 @@ class DQNAgent:
         return work
 
     def _finish_allreduce(self, work):
-        if not self._collective():
+        if not self._last_coll:
             return
-        world = self._dp_world()
         if work is not None:
             work.wait()  # orders the current stream after the collective; does not block the host on NCCL/RCCL
         if not self._ar_avg:
             flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
-            flat /= world
+            flat /= self._dp_world()
 
     # ---- misc --------------------------------------------------------------------------------------------
     def __repr__(self):
