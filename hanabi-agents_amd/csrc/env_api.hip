@@ -254,11 +254,12 @@ static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.flags = e->cfg.flags;
   a.ev_start = e->ev_start;
   a.ev_stop = e->ev_stop;
-  // automatic: 16 games per wavefront (two wavefronts per SIMD at 32 768 games), 32 when only the bit-packed rows leave
-  // the kernel AND the batch is large enough to keep two such wavefronts per SIMD. Measured r02, packed: 262 144 games
-  // 26.9 us (32) vs 36.2 us (16); 32 768 games 10.8 vs 11.5 us alone but 14.2 vs 12.5 us inside the training loop, where
-  // the kernel shares the CUs with the learner. int8 rows: 13.3 (16) vs 14.2 us (32). Results do not depend on it.
-  const int gpw = e->gpw ? e->gpw : ((a.obs_bits && !a.obs && e->n >= 131072) ? 32 : 16);
+  // automatic: 32 games per wavefront when only the bit-packed rows leave the kernel and the batch is >= 32 768 games (one
+  // wavefront per SIMD there, every phase wider), 16 otherwise (int8 rows: their stores want two wavefronts per SIMD; small
+  // batches: more wavefronts). Measured r02, packed: 262 144 games 26.9 us (32) vs 36.2 us (16); 32 768 games 9.2 vs 9.7 us alone
+  // and, with the selection fused in, 14.8 vs 17.5 us inside the training loop (0.142 vs 0.144 ms per step). int8 rows:
+  // 13.3 (16) vs 14.2 us (32). Results do not depend on it.
+  const int gpw = e->gpw ? e->gpw : ((a.obs_bits && !a.obs && e->n >= 32768) ? 32 : 16);
   hb::LaunchFn fn = gpw == 8 ? e->var->g8 : (gpw == 16 ? e->var->g16 : (gpw == 32 ? e->var->g32 : e->var->g64));
   fn(a, static_cast<hipStream_t>(stream));
   HB_HIP(hipGetLastError());

@@ -218,7 +218,7 @@ int hb_rule_act(const hb_config* cfg, const uint32_t* state_rows_dev, int64_t n_
                 int32_t* fired_dev, void* stream);
 
 /* Tuning knob for measurements: games handled per 64-lane wavefront (8, 16, 32 or 64); 0 (the default) picks 16,
- * or 32 for a packed-only step over >= 131072 games. The results do not depend on it.  */
+ * or 32 for a packed-only step over >= 32768 games. The results do not depend on it.  */
 int hb_env_set_games_per_wave(hb_env* env, int32_t g);
 
 /* Deck-pool refill placement. Every game keeps its NEXT deck pre-shuffled in HBM, so a re-deal inside
