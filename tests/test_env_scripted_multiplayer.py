@@ -1,4 +1,4 @@
-"""Hand-worked 3- and 5-player scenarios on explicit decks: what the 2-player KATs of
+"""Hand-worked 3-, 4- and 5-player scenarios on explicit decks: what the 2-player KATs of
 test_oracle_env.py cannot see — observer-relative actor / target bits of the last-action section for P >= 3, reveal
 bitmasks with hand size 4, knowledge shifting after a play, missing-card flags once the deck has run out, and "exactly P
 more moves after the last draw". Every expected bit position below is derived by hand from the section formulae of A.6,
@@ -191,12 +191,62 @@ def scenario_five_players(eng):
     assert ones(o, FLAGS5, DECK5) == sorted(FLAGS5 + r for r in short) and 1 <= len(short) <= 3
 
 
+# ---- 4 players, full game: obs 1041 = hands 300 | flags 4 | deck 34 | fireworks 25 | info 8 | life 3 | discards 50 |
+#      last action 57 (actor 4, type 4, target 4, colour 5, rank 5, outcome 4, position 4, card 25, scored/info 2) | knowledge 560
+FLAGS4, DECK4, FW4, INFO4, LIFE4, DISC4, LAST4, KN4, END4 = 300, 304, 338, 363, 371, 374, 424, 481, 1041
+
+
+def scenario_four_players(eng):
+    """Canonical deck, hands of 4: P0 = R1 R1 R1 R2, P1 = R2 R3 R3 R4, P2 = R4 R5 Y1 Y1, P3 = Y1 Y2 Y2 Y3; deck goes on Y3 Y4 Y4 Y5.
+    One successful play, then three misplays: the game ends on the third lost life with every point forfeited (A.5, A.7)."""
+    out = eng.observe()
+    o = out["obs"][0]
+    assert len(o) == END4 and out["legal"].shape[1] == 38          # 4 discards + 4 plays + 3 x 5 colour + 3 x 5 rank hints
+    assert [cards_in(o, 100 * k, 4) for k in range(3)] == [[1, 2, 2, 3], [3, 4, 5, 5], [5, 6, 6, 7]]
+    assert o[DECK4:FW4].sum() == 34 and o[LIFE4:DISC4].sum() == 3 and not o[LAST4:KN4].any()
+    # 1. P0 plays slot 0 (R1): success, draws Y3
+    out = eng.step([4 + 0])
+    o = out["obs"][0]                                             # observer: P1; P0 sits at offset (0 - 1) mod 4 = 3
+    assert out["reward"][0] == 1 and out["score"][0] == 1 and out["terminal"][0] == 0
+    assert ones(o, LAST4, KN4) == [LAST4 + 3, 428 + 0, 450 + 0, 454 + 0, 479]      # actor, play, position 0, card R1, scored
+    assert ones(o, FW4, INFO4) == [FW4 + 0] and o[DECK4:FW4].sum() == 33
+    assert cards_in(o, 200, 4) == [0, 0, 1, 7]                      # P0 (offset 3): R1 R1 R2 + the fresh Y3 in the last slot
+    # 2. P1 plays slot 1 (R3) on a red stack at 1: misplay, a life is lost, R3 goes to the discards, draws Y4
+    out = eng.step([4 + 1])
+    o = out["obs"][0]                                             # observer: P2
+    assert out["reward"][0] == 0 and out["score"][0] == 1 and out["terminal"][0] == 0
+    assert ones(o, LAST4, KN4) == [LAST4 + 3, 428 + 0, 450 + 1, 454 + 2]           # no scored / info bit
+    assert o[LIFE4:DISC4].sum() == 2 and ones(o, DISC4, LAST4) == [DISC4 + 5]      # R3's thermometer follows R1 (3) and R2 (2)
+    assert ones(o, FW4, INFO4) == [FW4 + 0] and o[INFO4:LIFE4].sum() == 8
+    assert cards_in(o, 200, 4) == [1, 2, 3, 8]                      # P1 (offset 3): R2 R3 R4 Y4
+    # 3. P2 plays slot 1 (R5): second misplay
+    out = eng.step([4 + 1])
+    o = out["obs"][0]                                             # observer: P3
+    assert ones(o, LAST4, KN4) == [LAST4 + 3, 428 + 0, 450 + 1, 454 + 4]
+    assert o[LIFE4:DISC4].sum() == 1 and ones(o, DISC4, LAST4) == [DISC4 + 5, DISC4 + 9]
+    assert out["terminal"][0] == 0 and out["agent_step_type"][0] == 0   # P3 has not moved yet: FIRST
+    # 4. P3 plays slot 3 (Y3) on an empty yellow stack: third misplay, the last life: game over, the point is forfeited
+    out = eng.step([4 + 3])
+    o = out["obs"][0]                                             # observer: P0
+    assert out["terminal"][0] == 1 and out["score"][0] == 0 and out["reward"][0] == -1
+    assert o[LIFE4:DISC4].sum() == 0 and ones(o, DISC4, LAST4) == [DISC4 + 5, DISC4 + 9, DISC4 + 10 + 5]
+    assert ones(o, LAST4, KN4) == [LAST4 + 3, 428 + 0, 450 + 3, 454 + 7]
+    assert out["agent_step_type"][0] == 2                          # LAST for the seat that would move next
+    assert out["agent_reward"][0] == 0                             # P0: +1 for its own play ... -1 at the end, summed since its move
+    st = eng.state()[0]
+    assert ((st[0] >> 10) & 7) == 0 and ((st[0] >> 19) & 3) != 0  # no lives left, game marked over
+
+
 def _decks(cfg_game, players, n=3):
     return np.tile(canonical_deck(O.make_config(cfg_game, players)), (n, 1))
 
 
 def test_three_player_scenario_on_the_oracle():
     scenario_three_players(OracleEngine("Hanabi-Full", 3, _decks("Hanabi-Full", 3)))
+
+
+def test_four_player_scenario_on_the_oracle():
+    scenario_four_players(OracleEngine("Hanabi-Full", 4, _decks("Hanabi-Full", 4)))
 
 
 def test_five_player_scenario_on_the_oracle():
@@ -213,3 +263,9 @@ def test_three_player_scenario_on_the_hip_kernel(packed):
 @pytest.mark.parametrize("packed", [False, True])
 def test_five_player_scenario_on_the_hip_kernel(packed):
     scenario_five_players(HipEngine("Hanabi-Full", 5, _decks("Hanabi-Full", 5), packed))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True])
+def test_four_player_scenario_on_the_hip_kernel(packed):
+    scenario_four_players(HipEngine("Hanabi-Full", 4, _decks("Hanabi-Full", 4), packed))
