@@ -805,10 +805,29 @@ class DQNAgent:
                 self._update_part2(self._g_idx, self._g_prios)
             self._graph2 = None
             return
+        if self._collective_in_graph():
+            # opt-in (HB_DP_GRAPH_COLLECTIVE=1, RCCL only): the all-reduce is captured INTO the graph between the two halves — one
+            # launch per update and no torch.distributed call on the host per update (≈50 us). RCCL's kernels are capturable;
+            # validated here with a one-rank group only (tests/test_distributed.py), hence not the default.
+            import torch.distributed as dist
+
+            flat = self._fl.flat_grad if self._fl is not None else self._flat_grad
+            with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
+                self.last_loss, self._g_idx, self._g_prios = self._update_part1()
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)
+                self._update_part2(self._g_idx, self._g_prios)
+            self._graph2 = None
+            return
         with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
             self.last_loss, self._g_idx, self._g_prios = self._update_part1()
         with torch.cuda.graph(self._graph2, pool=self._graph1.pool(), capture_error_mode="thread_local"):
             self._update_part2(self._g_idx, self._g_prios)
+
+    def _collective_in_graph(self):
+        import torch.distributed as dist
+
+        return (os.environ.get("HB_DP_GRAPH_COLLECTIVE") == "1" and self._graphs_enabled() and self._collective()
+                and not self.params.global_is_max and dist.get_backend(self.process_group) == "nccl")
 
     def _dp_world(self):
         import torch.distributed as dist
@@ -849,10 +868,13 @@ class DQNAgent:
         over the global batch, exactly."""
         import torch.distributed as dist
 
-        coll = self._last_coll = self._collective()   # (_finish_allreduce of the same update reuses the answer)
+        coll = self._collective()
         if self._fl is not None and self._fl.direct is not None and self._fl.direct != (not coll):
             raise RuntimeError("the process group changed after the FusedLearner was built: its gradient routing "
                                "(direct GEMM outputs vs packed all-reduce bucket) no longer matches the world size")
+        if coll and self._graph1 is not None and self._graph2 is None and self._graphs_enabled():
+            coll = False   # the collective lives inside the captured graph (_collective_in_graph): nothing to do on the host
+        self._last_coll = coll   # (_finish_allreduce of the same update reuses the answer)
         if not coll:
             return None
         flat = self._fl.flat_grad if self._fl is not None else self._flat_grad

@@ -228,7 +228,9 @@ def _rccl_worker(rank, world, port, out, lag):
     n = 256
     flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
     res = {}
-    for force in (False, True):
+    for force in (False, True, "graph"):
+        # "graph": the all-reduce captured inside the update graph (HB_DP_GRAPH_COLLECTIVE=1, opt-in)
+        os.environ["HB_DP_GRAPH_COLLECTIVE"] = "1" if force == "graph" else "0"
         torch.manual_seed(0)
         env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=n, seed=9, packed=True)
         params = RlaxRainbowParams(train_batch_size=64, experience_buffer_size=n * 8, layers=[256], compute_dtype="bfloat16",
@@ -236,12 +238,12 @@ def _rccl_worker(rank, world, port, out, lag):
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=40 + s),
                            device="cuda") for s in (0, 1)]
         for a in agents:
-            a.force_collective = force
+            a.force_collective = bool(force)
         sess = SelfPlaySession(env, agents)
         sess.run(30)
         torch.cuda.synchronize()
         fl = agents[0]._fl
-        assert fl.direct == (not force) and (agents[0]._graph2 is not None) == force and sess.grad_steps >= 26
+        assert fl.direct == (not force) and (agents[0]._graph2 is not None) == (force is True) and sess.grad_steps >= 26
         res[force] = dict(w=[torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]).cpu() for a in agents],
                           loss=float(agents[0].last_loss), illegal=env.illegal_count())
     torch.save(res, os.path.join(out, "rccl.pt"))
@@ -259,7 +261,8 @@ def test_collective_path_runs_on_rccl_with_one_rank(tmp_path, lag):
     mp.spawn(_rccl_worker, args=(1, port, str(tmp_path), lag), nprocs=1, join=True)
     r = torch.load(tmp_path / "rccl.pt")
     assert r[False]["illegal"] == r[True]["illegal"] == 0 and np.isfinite(r[True]["loss"])
-    for a, b in zip(r[False]["w"], r[True]["w"]):
+    for a, b, c in zip(r[False]["w"], r[True]["w"], r["graph"]["w"]):
         assert torch.isfinite(b).all()
         # same trajectory up to the rounding of the gradient route (30 steps of lr 1e-3: weights move by ~1e-2)
         assert (a - b).abs().max().item() < 2e-2
+        assert torch.equal(b, c)        # the collective captured inside the graph: same arithmetic, same order
