@@ -428,7 +428,7 @@ class DQNAgent:
             o, l = observations[1]
             try:
                 same = (o.data_ptr(), l.data_ptr(), actions.data_ptr(), rewards.data_ptr(), step_types.data_ptr(),
-                        self.last_obs.data_ptr(), self.experience._obs_t_buf.data_ptr()) == c[0]
+                        self.last_obs.data_ptr(), self.experience._obs_t_buf.data_ptr()) == c[0] and o.shape[0] == c[1]
             except AttributeError:
                 same = False
             if same:

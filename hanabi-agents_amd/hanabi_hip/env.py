@@ -152,11 +152,11 @@ class HanabiEnv:
         if actions_out is None:
             actions_out = torch.empty(self.n, dtype=torch.int32, device=self.device)
         c = self._sel_call
-        if c is None or c[0] != (q.data_ptr(), actions_out.data_ptr()):
+        if c is None or c[0] != (q.data_ptr(), actions_out.data_ptr(), q.numel(), actions_out.numel()):
             assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape == (self.n, self.num_actions)
             assert actions_out.dtype == torch.int32 and actions_out.is_contiguous() and actions_out.shape == (self.n,)
             # (the env's own output buffers never move: their addresses are converted once)
-            c = self._sel_call = ((q.data_ptr(), actions_out.data_ptr()), self.legal.data_ptr(),
+            c = self._sel_call = ((q.data_ptr(), actions_out.data_ptr(), q.numel(), actions_out.numel()), self.legal.data_ptr(),
                                   (self.obs_bits.data_ptr(), None, self.legal.data_ptr(), self.reward.data_ptr(),
                                    self.terminal.data_ptr(), self.agent_reward.data_ptr(), self.agent_step_type.data_ptr(),
                                    self.score.data_ptr()))

@@ -111,7 +111,8 @@ class ActorMFMA:
         """The two GEMMs of a policy call without the selection: q [N, A] fp32 (persistent buffer). For callers that fuse the
         selection into their next kernel (HanabiEnv.step_select)."""
         c = self._q_call
-        if c is None or c[0] != obs.data_ptr() or self.h is None or c[4] != self.h.data_ptr() or c[6] != support.data_ptr():
+        if (c is None or c[0] != obs.data_ptr() or c[1] != obs.shape[0] or self.h is None or c[4] != self.h.data_ptr()
+                or c[6] != support.data_ptr()):
             # a new operand (or re-allocated scratch): validate once, then reuse the converted arguments
             n = obs.shape[0]
             packed = obs.dtype == torch.int32
