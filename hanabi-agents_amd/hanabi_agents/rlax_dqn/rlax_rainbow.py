@@ -151,8 +151,12 @@ class DQNAgent:
             self.n_actions, 1)  # [A, K] (rlax_rainbow.py:253-254)
         # optix.adam(lr, eps=3.125e-5) has torch.optim.Adam's form, eps outside the sqrt
         on_gpu = self.device.type == "cuda"
+        # GPU paths that do not go through the FusedLearner (vanilla DQN, deeper nets): torch's single-launch fused Adam (same
+        # arithmetic as the foreach form, ~10 launches fewer per update: config 2 0.60 -> 0.52 ms per step); HB_ADAM_FUSED=0: foreach
+        fused_adam = on_gpu and os.environ.get("HB_ADAM_FUSED", "1") != "0"
         self.optimizer = torch.optim.Adam(self.online.parameters(), lr=params.learning_rate, betas=(0.9, 0.999),
-                                          eps=3.125e-5, capturable=on_gpu, foreach=True if on_gpu else None)
+                                          eps=3.125e-5, capturable=on_gpu, foreach=(True if on_gpu and not fused_adam else None),
+                                          fused=True if fused_adam else None)
         # one flat fp32 gradient buffer; every parameter's .grad is a view into it (single-bucket all-reduce,
         # no flatten/unflatten copies)
         plist = list(self.online.parameters())
