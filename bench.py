@@ -70,6 +70,7 @@ def _parse():
                     help="1: asynchronous actor (RlaxRainbowParams.actor_lag): double-buffered actor weights, the acting stream "
                          "never waits for an update; 0 (default): the reference's synchronous semantics")
     ap.add_argument("--main-priority", type=int, default=0, help="HIP priority of the acting stream (-1: high; default: the default stream)")
+    ap.add_argument("--event-every", type=int, default=1, help="attach the HIP timing events to every n-th env launch of the timed region")
     ap.add_argument("--no-async-variant", action="store_true", help="skip the second, asynchronous-actor measurement")
     ap.add_argument("--prime", type=int, default=24,
                     help="untimed SETUP steps before the W warm-up steps: the first updates capture the HIP graphs, pick the "
@@ -394,7 +395,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        env.set_profile_events(*ev[k])
+        if k % args.event_every == 0:
+            env.set_profile_events(*ev[k])
+        elif k % args.event_every == 1:
+            env.set_profile_events(None, None)
         one_step()
     if session is not None:
         session.flush()  # the last update's Adam / priority half (deferred behind the all-reduce when data-parallel)
@@ -411,7 +415,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev[::args.event_every])
     kernel_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     # with the agent's selection fused into the kernel (SelfPlaySession.fuse_select) a launch also reads the q row (4 A bytes) and
     # the acting seat's legal row (A bytes) per game; its 4-byte action is written instead of read
