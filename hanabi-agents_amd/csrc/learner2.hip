@@ -516,6 +516,53 @@ int launch_backward(const BwdArgs& a0, hipStream_t s) {
   return HB_OK;
 }
 
+// ---- scalar double-Q loss of the older agent (hanabi_agents/rlax_dqn/rlax_dqn.py:170-205), compact gradient -------------
+// One thread per sample, one workgroup (B <= 256). q values sit in "logits" rows of row stride rs with action a at column
+// a * cs (cs = 2: the scalar head stored as a 2-atom head whose second atom is never used, so that hb_c51_backward serves it
+// unchanged). td = r + gamma * q_target(s')[argmax_a q_online(s')] * (1 - terminal) - q_online(s)[a_tm1]; IS weight
+// ((1/P) ** beta) / max; loss = mean(w * 0.5 * td^2)  =>  dLoss/dq[b, a_tm1] = -w * td / B, written to dl[b, 0]
+// (dl rows are 64 floats; columns 1..63 are zeroed).
+template <typename T>
+__global__ __launch_bounds__(256) void dqn_loss_kernel(const T* __restrict__ q_on, const T* __restrict__ q_t, const int32_t* __restrict__ act,
+                                                       const float* __restrict__ rew, const float* __restrict__ term,
+                                                       const double* __restrict__ prios, const float* __restrict__ beta_dev,
+                                                       const float* __restrict__ disc, int B, int A, int cs, int rs,
+                                                       float* __restrict__ td_out, float* __restrict__ w_out, float* __restrict__ dl,
+                                                       const T* __restrict__ bias_on, const T* __restrict__ bias_t) {
+  __shared__ float red[8];
+  const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
+  const bool on = b < B;
+  const float beta = *beta_dev;
+  float ip = on ? static_cast<float>(1.0 / prios[b]) : (beta >= 0.f ? 0.f : INFINITY);
+  // max over the batch of (1/P) ** beta: attained at the largest (beta >= 0) or smallest 1/P (monotone map)
+  float ext = ip;
+  ext = beta >= 0.f ? wave_max(ext) : wave_min(ext);
+  if (lane == 0) red[wave] = ext;
+  __syncthreads();
+  float e2 = red[0];
+  for (int i = 1; i < (B + 63) / 64; ++i) e2 = beta >= 0.f ? fmaxf(e2, red[i]) : fminf(e2, red[i]);
+  if (!on) return;
+  const float w = powf(ip, beta) / powf(e2, beta);
+  const int a_tm1 = act[b];
+  const float q_tm1 = ld<T>(q_on, static_cast<long long>(b) * rs + a_tm1 * cs) + (bias_on ? ld<T>(bias_on, a_tm1 * cs) : 0.f);
+  const T* sel = q_on + static_cast<long long>(B + b) * rs;     // online net on obs_t: the double-Q selector
+  int best = 0;
+  float bv = -INFINITY;
+  for (int a = 0; a < A; ++a) {                                   // first maximum, like torch.argmax / jnp.argmax
+    const float v = ld<T>(sel, a * cs) + (bias_on ? ld<T>(bias_on, a * cs) : 0.f);
+    if (v > bv) { bv = v; best = a; }
+  }
+  float qt = ld<T>(q_t, static_cast<long long>(b) * rs + best * cs) + (bias_t ? ld<T>(bias_t, best * cs) : 0.f);
+  if (term[b] != 0.f) qt = 0.f;
+  const float td = rew[b] + disc[b] * qt - q_tm1;
+  td_out[b] = td;
+  w_out[b] = w;
+  float4* row = reinterpret_cast<float4*>(dl + static_cast<long long>(b) * 64);
+  row[0] = make_float4(-w * td / static_cast<float>(B), 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 1; i < 16; ++i) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace
 
 extern "C" {
@@ -546,6 +593,33 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
   else if (dtype == 2) HB_C51S(__half);
   else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
 #undef HB_C51S
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_dqn_loss_sparse(const void* q_online_dev, const void* q_target_dev, int32_t dtype, const int32_t* act_dev, const float* rew_dev,
+                       const float* term_dev, const double* prios_dev, const float* beta_dev, const float* disc_dev, int64_t batch,
+                       int32_t n_actions, int32_t col_stride, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev,
+                       const void* bias_online_dev, const void* bias_target_dev, void* stream) {
+  if (!q_online_dev || !q_target_dev || !act_dev || !rew_dev || !term_dev || !prios_dev || !beta_dev || !disc_dev || !td_dev ||
+      !w_dev || !dl_dev)
+    return fail(HB_ERR_INVALID, "null argument");
+  if (batch <= 0) return HB_OK;
+  if (batch > 256) return fail(HB_ERR_INVALID, "batch must be <= 256");
+  if (n_actions < 1 || col_stride < 1 || row_stride < (n_actions - 1) * col_stride + 1) return fail(HB_ERR_INVALID, "bad action layout");
+  if (reinterpret_cast<uintptr_t>(dl_dev) & 15u) return fail(HB_ERR_ALIGN, "dl_dev must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int B = static_cast<int>(batch);
+#define HB_DQNL(T)                                                                                                           \
+  hipLaunchKernelGGL((dqn_loss_kernel<T>), dim3(1), dim3(256), 0, s, static_cast<const T*>(q_online_dev),                      \
+                     static_cast<const T*>(q_target_dev), act_dev, rew_dev, term_dev, prios_dev, beta_dev, disc_dev, B, n_actions, \
+                     col_stride, row_stride, td_dev, w_dev, dl_dev, static_cast<const T*>(bias_online_dev),                    \
+                     static_cast<const T*>(bias_target_dev))
+  if (dtype == 0) HB_DQNL(float);
+  else if (dtype == 1) HB_DQNL(__hip_bfloat16);
+  else if (dtype == 2) HB_DQNL(__half);
+  else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+#undef HB_DQNL
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

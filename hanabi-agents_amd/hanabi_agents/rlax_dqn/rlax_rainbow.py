@@ -196,6 +196,7 @@ class DQNAgent:
         self._pending = None          # (all-reduce handle, eager part-2 arguments) between update_begin / update_finish
         self._disc = params.discount  # scalar gamma, or the [B] tensor gamma^m of the current n-step batch
         self._fl = None             # FusedLearner (GPU, C51, one hidden layer), built at the first update
+        self._fv = None             # FusedVanillaLearner (GPU, scalar double-DQN, uniform replay), built at the first update
         self.use_fused_learner = use_fused_learner
         self.use_mfma_actor = True   # csrc/actor.hip when the FusedLearner can feed it; False = cast + library GEMMs + hb_policy_act
         self._draws = 0             # Philox draw counter of the fused sampler
@@ -224,6 +225,8 @@ class DQNAgent:
         """mean(td * w_IS) of the most recent update (rlax_rainbow.py:196)."""
         if self._fl is not None and self._last_loss is None:
             return self._fl.loss()
+        if self._fv is not None and self._last_loss is None:
+            return self._fv.loss()
         return self._last_loss
 
     @last_loss.setter
@@ -586,6 +589,8 @@ class DQNAgent:
     def _refresh_target_cache(self):
         if self._fl is not None:
             self._fl.refresh_target()
+        if self._fv is not None:
+            self._fv.refresh_target()
         if self._trg_cache is None:
             return
         with torch.no_grad():  # IN PLACE: captured graphs hold these tensors
@@ -652,6 +657,16 @@ class DQNAgent:
                 self.experience.sum_tree.set_lazy_top(True)
         return self._fl
 
+    def _fused_vanilla(self):
+        """hanabi_agents.rlax_dqn.fused_vanilla.FusedVanillaLearner when applicable (GPU, scalar head, one hidden layer,
+        uniform replay, batch <= 256)."""
+        if self._fv is None and self.use_fused_learner:
+            from .fused_vanilla import FusedVanillaLearner
+
+            if FusedVanillaLearner.supports(self):
+                self._fv = FusedVanillaLearner(self)
+        return self._fv
+
     def _sample_indices(self):
         b = self.params.train_batch_size
         if self.params.use_priority and self._fl is not None:
@@ -686,6 +701,11 @@ class DQNAgent:
             self._note_local_is_max(prios)
             td, _ = fl.part1(indices, prios, gathered=gathered)
             return None, indices, td  # the loss value is formed on demand (last_loss) from td and the IS weights
+        fv = self._fused_vanilla()
+        if fv is not None:
+            indices, prios = self._sample_indices()
+            td = fv.part1(indices, prios)
+            return None, indices, td   # (the loss value is formed on demand: last_loss)
         indices, prios, tr = self._sample()
         self._note_local_is_max(prios)
         if self.params.resample_noise:
@@ -719,6 +739,8 @@ class DQNAgent:
             self._fl.part2()
         else:
             self.optimizer.step()
+            if self._fv is not None:
+                self._fv.refresh_online()   # the GEMM-dtype copies follow the fp32 master weights
         if self.params.use_priority and not self.split_update:
             # (running this on a forked graph branch beside Adam was measured slower: 0.216 vs 0.190 ms per update)
             self.experience.update_priorities_dev(indices, new_prios)
@@ -781,6 +803,8 @@ class DQNAgent:
         self._gen.set_state(snap["gen"])
         self._last_loss = snap["last_loss"]
         self._eff_cache = None
+        if self._fv is not None:
+            self._fv.refresh_all()
         if self._fl is not None and not self.actor_lag:   # (actor_lag: the warm-up updates never touch the actor's weight sets)
             self._fl.actor_stale = True
 
@@ -988,6 +1012,8 @@ class DQNAgent:
             else:
                 self.optimizer.load_state_dict(sd["optimizer"])
                 self._trg_cache = None
+                if self._fv is not None:
+                    self._fv.refresh_all()
             self._eff_cache = None
             # Capturing the update graphs runs warm-up updates, which would otherwise happen (and change the weights)
             # at the first update() after the resume: capture now, on the restored replay, then restore once more.
@@ -1017,4 +1043,6 @@ class DQNAgent:
         self.target.load_state_dict(torch.load(trg_weights_file, map_location=self.device, weights_only=True))
         if self._fl is not None:
             self._fl.refresh_effective()
+        if self._fv is not None:
+            self._fv.refresh_online()
         self._refresh_target_cache()

@@ -419,6 +419,17 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
                        int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev, float* update_counter_dev,
                        const void* bias_online_dev, const void* bias_target_dev, void* stream);
 
+/* hb_dqn_loss_sparse: the scalar double-Q loss of the older agent (hanabi_agents/rlax_dqn/rlax_dqn.py:170-205: td = r + g * (1 -
+ * terminal) * q_target(s')[argmax q_online(s')] - q_online(s)[a], loss = mean(w_IS * 0.5 * td^2)) on precomputed q values, in the
+ * same compact-gradient form as hb_c51_loss_sparse: q_online_dev [2B, row_stride] (rows 0..B-1: obs_tm1, B..2B-1: obs_t),
+ * q_target_dev [B, row_stride] (obs_t), action a at column a * col_stride (col_stride 2 stores the scalar head as a 2-atom head
+ * whose second atom is unused, so that hb_c51_backward(n_atoms = 2) computes its backward pass); biases in `dtype` at the same
+ * columns (may be NULL). Outputs td [B], IS weights [B], dl [B, 64] with dl[b, 0] = dLoss/dq[b, act[b]]. batch <= 256.       */
+int hb_dqn_loss_sparse(const void* q_online_dev, const void* q_target_dev, int32_t dtype, const int32_t* act_dev, const float* rew_dev,
+                       const float* term_dev, const double* prios_dev, const float* beta_dev, const float* disc_dev, int64_t batch,
+                       int32_t n_actions, int32_t col_stride, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev,
+                       const void* bias_online_dev, const void* bias_target_dev, void* stream);
+
 /* hb_c51_backward: everything between that loss and the first layer's weight gradient, in ONE launch (the `jax.grad` of
  * rlax_rainbow.py:203-213 through the output layer and the ReLU of noisy_mlp.py:176-185), from the compact gradient:
  *   dh_dev  [B, hidden]  (dtype)  = (hidden_dev[b, j] > 0) * sum_k dl[b, k] * w2[j, act[b] * n_atoms + k]

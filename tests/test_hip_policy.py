@@ -643,3 +643,61 @@ def test_selection_fused_into_the_q_gemm_equals_the_separate_launch(n, A, atoms,
         assert torch.equal(q_f, act.q)
         assert torch.equal(a_f, a_s), f"rep {rep}: {(a_f != a_s).sum().item()} actions differ"
         assert bool((legal.gather(1, a_f.long()[:, None]) == 1).all())
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_vanilla_learner_equals_autograd_learner(dtype):
+    """FusedVanillaLearner (gather, 2 GEMMs, hb_dqn_loss_sparse, hb_c51_backward with the scalar head stored as a 2-atom head,
+    dW1 GEMM, torch's fused Adam) against the torch-autograd form of the same update (use_fused_learner=False) on the same
+    agent state: per-sample td, loss, every gradient and the weights after 5 updates — exact arithmetic up to summation
+    order at fp32, within the bf16 tolerances at bf16."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
+
+    n, obs_len, n_act = 256, 658, 20
+    params = RlaxRainbowParams(distributional=False, use_priority=False, train_batch_size=n, experience_buffer_size=2 * n,
+                               target_update_period=2, seed=11, compute_dtype=dtype)
+    fused = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False)
+    plain = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False, use_fused_learner=False)
+    rng = np.random.default_rng(0)
+    o1, o2 = (rng.integers(0, 2, (n, obs_len)).astype(np.int8) for _ in range(2))
+    legal = np.ones((n, n_act), np.int8)
+    act, rew = rng.integers(0, n_act, n), rng.integers(-1, 3, n).astype(np.float32)
+    st = rng.integers(1, 3, n)
+    for a in (fused, plain):
+        with torch.no_grad():
+            for b in a.online.biases:
+                b.fill_(0.05)
+            for p, q in zip(a.target.parameters(), a.online.parameters()):
+                p.copy_(q * 0.9)
+        a.add_experience_first((None, (o1, legal)), np.zeros(n))
+        a.add_experience((None, (o2, legal)), act, rew, st)
+        a.experience.sample_indices_dev = lambda b, a=a: torch.arange(b, device=a.device)
+    assert fused._fused_vanilla() is not None and plain._fused_vanilla() is None
+    fused._fv.refresh_all()                      # (the biases and the target were changed after construction)
+    f32 = dtype == "float32"
+    # (bf16 weights after 5 Adam steps: a gradient near zero may take the other sign under rounding and Adam's first steps
+    # move every weight by ~lr whatever the gradient's size: the bound of tolerance.py, 2 * 5 * lr)
+    tol = dict(td=1e-4, g=2e-3, w=2e-4) if f32 else dict(td=TOLERANCE["bfloat16"]["td_abs"] * 4, g=0.06,
+                                                         w=TOLERANCE["bfloat16"]["weights_after_5_steps_max_abs"])
+    # first update: td, loss and gradients (the plain agent leaves them in p.grad as well)
+    fused._flat_grad.zero_()
+    _, _, td_f = fused._update_part1()
+    loss_p, _, td_p = plain._update_part1()
+    td_f, td_p = td_f.clone(), td_p.clone()
+    assert torch.allclose(td_f.abs(), td_p, atol=tol["td"], rtol=1e-3)
+    assert abs(float(fused.last_loss) - float(loss_p)) <= 2e-3 * abs(float(loss_p)) + 1e-6
+    for p, q in zip(fused.online.parameters(), plain.online.parameters()):
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= tol["g"] * scale + 1e-8, (p.shape, float((p.grad - q.grad).abs().max()), scale)
+    fused._update_part2(None, None)
+    plain._update_part2(None, None)
+    for _ in range(4):
+        fused.update()
+        plain.update()
+    for p, q in zip(list(fused.online.parameters()) + list(fused.target.parameters()),
+                    list(plain.online.parameters()) + list(plain.target.parameters())):
+        assert float((p - q).abs().max()) <= tol["w"] + 1e-3 * float(q.abs().max())
+        assert float((p - q).abs().mean()) <= 0.05 * tol["w"] + 1e-6     # ... and on average they agree far better
