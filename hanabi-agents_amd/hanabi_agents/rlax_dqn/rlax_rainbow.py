@@ -280,7 +280,25 @@ class DQNAgent:
         if pa is None:
             pa = self._plain_actor = ActorMFMA(self.obs_len, hidden, self.n_actions, 2, kp, self.device)   # (only its hidden half is used)
             pa.stale = True
+        fv = self._fv
+        if (pa.stale or self._eff_cache is None) and fv is not None and fv.cd == torch.bfloat16:
+            # the learner keeps bf16 copies of the online weights current: transpose W1 from there (one launch, cached job
+            # table) and refresh the fp32 image of the bf16 output layer (two strided copies) — no allocation, no casts
+            if getattr(pa, "fv_jobs", None) is None:
+                pa.w2f = torch.empty(hidden, self.n_actions, dtype=torch.float32, device=self.device)
+                pa.b2f = torch.empty(self.n_actions, dtype=torch.float32, device=self.device)
+                jobs = (K.HbPackJob * 1)()
+                j = jobs[0]
+                j.w, j.bias, j.wt, j.bias_out = fv.w1cat.data_ptr(), fv.b1cat.data_ptr(), pa.w1t.data_ptr(), pa.b1.data_ptr()
+                j.k_rows, j.n_cols, j.w_ld, j.group_cols, j.k_pad = self.obs_len, hidden, fv.w1cat.stride(0), 0, kp
+                pa.fv_jobs = jobs
+            K.check(K.lib().hb_actor_pack_weights(pa.fv_jobs, 1, K.current_stream()))
+            pa.w2f.copy_(fv.w2st[0][:, 0:2 * self.n_actions:2])
+            pa.b2f.copy_(fv.b2st[0][0:2 * self.n_actions:2])
+            pa.stale = False
+            self._eff_cache = True
         if pa.stale or self._eff_cache is None:
+            pa.fv_jobs = None   # (this path re-creates w2f / b2f)
             w1, w2 = self.online.weights[0].detach(), self.online.weights[1].detach()
             b1, b2 = self.online.biases[0].detach(), self.online.biases[1].detach()
             w1p = torch.zeros(kp, hidden, dtype=torch.bfloat16, device=self.device)

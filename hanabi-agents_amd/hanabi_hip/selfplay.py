@@ -64,6 +64,7 @@ class SelfPlaySession:
         lagging = any(getattr(a, "actor_lag", 0) for a in agents)
         self._stream_per_agent = (self._dp or lagging) if stream_per_agent is None else bool(stream_per_agent)
         self._lstreams = {}
+        self.max_learner_streams = 2
         if self.learner_stream is not None and split_update:
             for a in agents:
                 if hasattr(a, "set_split_update"):
@@ -158,9 +159,15 @@ class SelfPlaySession:
             return self.learner_stream
         ls = self._lstreams.get(id(agent))
         if ls is None:
-            ls = self._lstreams[id(agent)] = (self.learner_stream if not self._lstreams else
-                                              self._stream_factory() if self._stream_factory else
-                                              torch.cuda.Stream(device=self.env.device, priority=self.learner_stream.priority))
+            # at most max_learner_streams distinct streams, dealt round-robin in seat order: consecutive seats' updates never
+            # share a stream (what "per agent" is for), and a 5-seat session does not open 5 high-priority streams
+            made = list(dict.fromkeys(self._lstreams.values()))
+            if len(made) >= self.max_learner_streams:
+                ls = made[len(self._lstreams) % self.max_learner_streams]
+            else:
+                ls = (self.learner_stream if not made else self._stream_factory() if self._stream_factory else
+                      torch.cuda.Stream(device=self.env.device, priority=self.learner_stream.priority))
+            self._lstreams[id(agent)] = ls
         return ls
 
     def _ready(self, agent):
