@@ -393,13 +393,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev_t0, ev_main_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_t0.record()
     for k in range(args.steps):
         if k % args.event_every == 0:
             env.set_profile_events(*ev[k])
         elif k % args.event_every == 1:
             env.set_profile_events(None, None)
         one_step()
+    ev_main_end.record()   # the acting stream's last launch of the timed region; what follows is the learner streams' drain
     if session is not None:
         session.flush()  # the last update's Adam / priority half (deferred behind the all-reduce when data-parallel)
     host_enqueue_s = time.perf_counter() - t0  # host-side launch time of the timed region (GPU still draining)
@@ -458,6 +461,10 @@ def main():
         },
         "grad_steps_per_sec": world * 0 + (grad_steps / dt if grad_steps else 0.0),
         "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
+        # how the timed region splits: the acting stream's K steps, then the learner streams finishing the last update(s) plus
+        # the final synchronisation (a fixed cost per run: 20-step runs read ~10 % slower per step than 200-step runs)
+        "timed_region_ms": {"total": dt * 1e3, "acting_stream": ev_t0.elapsed_time(ev_main_end),
+                            "drain_and_sync": dt * 1e3 - ev_t0.elapsed_time(ev_main_end)},
         "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_env_step": bytes_per_step,
