@@ -36,3 +36,25 @@ def test_bench_under_a_launcher_keeps_its_world():
     r = _run(env, args=("--gpus", "1", "--launch-check"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["world"] == 1
+
+
+def test_bench_options_and_hardware_queue_default():
+    """The driver's flags and this round's additions parse; importing bench.py sets GPU_MAX_HW_QUEUES=2 unless the environment
+    already chose a value (with ROCm's default of 4 the multi-rank update path ran 3x slower); without a GPU the
+    benchmark itself refuses to run instead of falling back to anything."""
+    code = ("import os, sys; sys.argv=['bench.py','--gpus','1','--steps','20','--warmup','5','--actor-lag','1','--event-every','4',"
+            "'--no-async-variant','--vanilla']; import bench; a=bench.parse(); "
+            "print(os.environ['GPU_MAX_HW_QUEUES'], a.steps, a.warmup, a.actor_lag, a.event_every, a.prime, a.vanilla)")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["2", "20", "5", "1", "4", "24", "True"]
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.stdout.split()[0] == "4"
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
