@@ -9,7 +9,8 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         key = next((w for w in want if w in name), None)
         if key is None:
             continue
-        kk = key + ("<0> hidden" if "ILi0E" in name or "<0>" in name else "<1> q" if "ILi1E" in name or "<1>" in name else "")
+        kk = key + ("<0> hidden (int8 rows)" if "ILi0E" in name or "<0>" in name else "<1> q" if "ILi1E" in name or "<1>" in name else
+                    "<2> hidden (bit rows)" if "ILi2E" in name or "<2>" in name else "")
         e = out.setdefault(kk, {})
         c = e.setdefault(r["Counter_Name"], [0.0, 0])
         c[0] += float(r["Counter_Value"]); c[1] += 1
