@@ -58,3 +58,34 @@ def test_bench_options_and_hardware_queue_default():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_measurement_contract():
+    """`python bench.py` on the GPU: exactly one JSON line on stdout with the contract's keys (metric / value / unit / n_gpus /
+    steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload), the roofline
+    object of the dominant kernel (bound, achieved, peak, unit, frac, traffic) and the CPU baselines; value = games x steps / time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--games", "2048",
+                        "--cpu-sample-games", "256", "--cpu-sample-steps", "20"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_learner", "grad_steps_per_sec"):
+        assert k in d, k
+    assert d["metric"] == "env_steps_per_sec" and d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2048 * 6 / (d["ms_per_step"] * 6 / 1e3)) <= 1e-6 * d["value"]
+    r_ = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r_, k
+    assert r_["bound"] == "hbm" and r_["unit"] == "GB/s" and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["async_actor"]["actor_lag"] == 1 and d["async_actor"]["env_steps_per_sec"] > 0

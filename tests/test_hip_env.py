@@ -274,7 +274,7 @@ def test_arbitrary_uids_all_variants(game, players):
 
 
 @pytest.mark.parametrize("game,players,n", [("Hanabi-Full", 2, 3000), ("Hanabi-Full", 5, 700), ("Hanabi-Small", 3, 500),
-                                            ("Hanabi-Very-Small", 2, 130)])
+                                            ("Hanabi-Very-Small", 2, 130), ("Hanabi-Full", 2, 32768)])
 def test_selection_fused_into_the_env_step_equals_select_then_step(game, players, n):
     """hb_env_step_select_packed (each game's lane picks its move from q and the legal mask by hb_policy_select's rule and
     draws, then applies it) against hb_policy_select followed by hb_env_step_packed: same actions, and the same state rows,
