@@ -770,7 +770,44 @@ __global__ __launch_bounds__(NT7) void gemm_v8(const Args a) {
   STAMP(63);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "thin" GEMM (co-residency study, scripts/thin_probe.py): ONE wavefront per workgroup, a 32 x 32 output tile, operands
+// fetched straight from global memory into MFMA fragments (no LDS), few registers — a kernel that fits in what an actor-GEMM
+// workgroup leaves free on its CU (48 VGPRs per SIMD, 27 KB of LDS) and can therefore run WHILE that GEMM runs.
+//   out[M, N] bf16 = relu?(x[M, K] @ wt[N, K]^T), both operands k-contiguous, K % 32 == 0, M % 32 == 0, N % 32 == 0
+__global__ __launch_bounds__(64) void gemm_thin(const Args a) {
+  // 32 rows x 16 columns per wavefront: 8 accumulator registers, three operand fragments, 32-bit offsets
+  const int lane = threadIdx.x;
+  const int lr = lane & 15, kq = lane >> 4;
+  const unsigned xo = (static_cast<unsigned>(blockIdx.x) * 32u + lr) * static_cast<unsigned>(a.k) * 2u + kq * 16u;
+  const unsigned wo = (static_cast<unsigned>(blockIdx.y) * 16u + lr) * static_cast<unsigned>(a.k) * 2u + kq * 16u;
+  const unsigned half = 32u * static_cast<unsigned>(a.k);   // byte distance of the second 16-row tile
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wt);
+  f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 1
+  for (unsigned kb = 0; kb < static_cast<unsigned>(a.k) * 2u; kb += 64u) {
+    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xb + xo + kb), x1 = *reinterpret_cast<const bf16x8*>(xb + xo + kb + half);
+    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wb + wo + kb);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1, acc1, 0, 0, 0);
+  }
+  // acc_m[j] = out[row 32 bx + 16 m + (lane & 15)][col 16 by + 4 (lane >> 4) + j]
+  const long long r0 = static_cast<long long>(blockIdx.x) * 32;
+  const int c0 = static_cast<int>(blockIdx.y) * 16;
+  *reinterpret_cast<uint2*>(a.out + (r0 + lr) * a.n + c0 + 4 * kq) = make_uint2(pack_bf16(acc0[0], acc0[1]), pack_bf16(acc0[2], acc0[3]));
+  *reinterpret_cast<uint2*>(a.out + (r0 + 16 + lr) * a.n + c0 + 4 * kq) = make_uint2(pack_bf16(acc1[0], acc1[1]), pack_bf16(acc1[2], acc1[3]));
+}
+
 }  // namespace
+
+extern "C" int probe_thin_gemm(const void* x, long long m, int k, const void* wt, int n, void* out, void* stream) {
+  if (k % 32 || n % 16 || m % 32) return -1;
+  Args a{static_cast<const __hip_bfloat16*>(x), static_cast<const __hip_bfloat16*>(wt), static_cast<__hip_bfloat16*>(out), nullptr, m, k, n};
+  hipLaunchKernelGGL(gemm_thin, dim3(static_cast<unsigned>(m / 32), static_cast<unsigned>(n / 16)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 extern "C" int probe_gemm(int variant, int stamped, const void* x, long long m, int k, const void* wt, int n, void* out,
                           unsigned long long* stamps, void* stream) {
