@@ -563,6 +563,66 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(const T* __restrict__ q_o
   for (int i = 1; i < 16; ++i) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---- "thin" GEMM: the learner's forward products in a form that runs BESIDE an actor-GEMM workgroup --------------------
+// While hb_actor_hidden / hb_actor_q run, every CU holds one of their workgroups (232 VGPRs x 2 wavefronts per SIMD, 133 KB
+// of LDS): 48 VGPRs per SIMD and 27 KB of LDS are left, and a library GEMM launched by the other seat's update waits until
+// they retire. This kernel fits in the remainder — ONE wavefront per workgroup, a 32 x 16 output tile, MFMA fragments loaded
+// straight from global memory (no LDS), 36 VGPRs — so the update's forward pass proceeds WHILE the policy GEMMs run
+// (scripts/thin_probe.py: it finishes inside a running hb_actor_q and lengthens that GEMM by 3 %).
+//   out[b][m, n] = act(sum_k x[b][m, k] * wt[b][n, k] + bias[n]),  x and wt k-contiguous bf16, fp32 accumulation in k order
+typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
+struct ThinArgs {
+  const unsigned char* x;    // bf16 [batch][M][ldx]
+  const unsigned char* wt;   // bf16 [batch][N][ldw]
+  const __hip_bfloat16* bias;  // [N] or NULL
+  __hip_bfloat16* out;       // [batch][M][ldo]
+  unsigned ldx, ldw, ldo;    // in elements
+  unsigned x_bs, w_bs, o_bs; // batch strides in elements
+  int k, relu;
+  unsigned n_tiles;        // first column tile (16 columns each) this launch covers
+};
+__device__ __forceinline__ uint32_t tg_pack(float lo, float hi) {
+  const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+  return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+}
+__global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const int batch) {
+  // One wavefront per (row tile, column tile); it walks the batch itself, so a launch never has more workgroups than
+  // (m / 32) * (n / 16): for the learner's shapes that is 1 024 = one wavefront per SIMD of the chip, which leaves an
+  // actor-GEMM workgroup arriving LATER its 464 registers per SIMD as well.
+  const int lane = threadIdx.x;
+  const unsigned lr = lane & 15, kq = lane >> 4;
+  const unsigned ct = blockIdx.y + a.n_tiles;   // (n_tiles: first column tile of this launch)
+  const unsigned c = ct * 16u + 4u * kq;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  if (a.bias) {
+    b0 = __bfloat162float(a.bias[c]); b1 = __bfloat162float(a.bias[c + 1]); b2 = __bfloat162float(a.bias[c + 2]); b3 = __bfloat162float(a.bias[c + 3]);
+  }
+  const unsigned half = 32u * a.ldx;   // byte distance of the second 16-row tile
+#pragma unroll 1
+  for (int z = 0; z < batch; ++z) {
+    const unsigned xo = (z * a.x_bs + (blockIdx.x * 32u + lr) * a.ldx + kq * 8u) * 2u;
+    const unsigned wo = (z * a.w_bs + (ct * 16u + lr) * a.ldw + kq * 8u) * 2u;
+    tg_f32x4 acc0 = tg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 1
+    for (unsigned kb = 0; kb < static_cast<unsigned>(a.k) * 2u; kb += 64u) {
+      const tg_bf16x8 x0 = *reinterpret_cast<const tg_bf16x8*>(a.x + xo + kb), x1 = *reinterpret_cast<const tg_bf16x8*>(a.x + xo + kb + half);
+      const tg_bf16x8 w0 = *reinterpret_cast<const tg_bf16x8*>(a.wt + wo + kb);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1, acc1, 0, 0, 0);
+    }
+    // acc_m[j] = out[row 32 bx + 16 m + (lane & 15)][col 16 by + 4 (lane >> 4) + j]
+    float v[8] = {acc0[0] + b0, acc0[1] + b1, acc0[2] + b2, acc0[3] + b3, acc1[0] + b0, acc1[1] + b1, acc1[2] + b2, acc1[3] + b3};
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    __hip_bfloat16* o = a.out + z * static_cast<size_t>(a.o_bs) + static_cast<size_t>(blockIdx.x * 32u + lr) * a.ldo + c;
+    *reinterpret_cast<uint2*>(o) = make_uint2(tg_pack(v[0], v[1]), tg_pack(v[2], v[3]));
+    *reinterpret_cast<uint2*>(o + 16u * static_cast<size_t>(a.ldo)) = make_uint2(tg_pack(v[4], v[5]), tg_pack(v[6], v[7]));
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -593,6 +653,33 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
   else if (dtype == 2) HB_C51S(__half);
   else return fail(HB_ERR_INVALID, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
 #undef HB_C51S
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
+                 int32_t ldx, int32_t ldw, int32_t ldo, int32_t batch, int64_t x_batch_stride, int64_t w_batch_stride,
+                 int64_t out_batch_stride, int32_t relu, void* stream) {
+  if (!x_dev || !wt_dev || !out_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (m <= 0 || n <= 0 || batch <= 0) return HB_OK;
+  if (m % 32 || n % 16 || k % 32 || k < 32) return fail(HB_ERR_INVALID, "need m % 32 == 0, n % 16 == 0, k % 32 == 0");
+  if (ldx < k || ldw < k || ldo < n || ldx % 8 || ldw % 8 || ldo % 4) return fail(HB_ERR_INVALID, "bad leading dimensions");
+  if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) || (reinterpret_cast<uintptr_t>(wt_dev) & 15u) || (reinterpret_cast<uintptr_t>(out_dev) & 7u))
+    return fail(HB_ERR_ALIGN, "x / wt must be 16-byte aligned, out 8-byte aligned");
+  const int64_t xe = (batch - 1) * x_batch_stride + m * static_cast<int64_t>(ldx), we = (batch - 1) * w_batch_stride + n * static_cast<int64_t>(ldw);
+  if (xe >= (1LL << 30) || we >= (1LL << 30)) return fail(HB_ERR_INVALID, "operands beyond the kernel's 32-bit offsets");
+  ThinArgs a{static_cast<const unsigned char*>(x_dev), static_cast<const unsigned char*>(wt_dev),
+             static_cast<const __hip_bfloat16*>(bias_dev), static_cast<__hip_bfloat16*>(out_dev), static_cast<unsigned>(ldx),
+             static_cast<unsigned>(ldw), static_cast<unsigned>(ldo), static_cast<unsigned>(x_batch_stride),
+             static_cast<unsigned>(w_batch_stride), static_cast<unsigned>(out_batch_stride), k, relu, 0u};
+  // at most 1 024 workgroups (= wavefronts) per launch: one per SIMD of the chip, so that an actor-GEMM workgroup arriving
+  // while this kernel runs still finds its registers; wider outputs take several launches
+  const unsigned tiles = static_cast<unsigned>(n / 16), gx = static_cast<unsigned>(m / 32), cap = gx >= 1024u ? 1u : 1024u / gx;
+  for (unsigned t0 = 0; t0 < tiles; t0 += cap) {
+    a.n_tiles = t0;
+    hipLaunchKernelGGL(thin_gemm_kernel, dim3(gx, tiles - t0 < cap ? tiles - t0 : cap), dim3(64), 0, static_cast<hipStream_t>(stream), a,
+                       batch);
+  }
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

@@ -21,6 +21,8 @@ The reference computes the same thing through jax.grad of the loss (hanabi_agent
 the hand-written backward is exact, not an approximation. Both halves (before / after the optional collective)
 are captured into HIP graphs by the agent.
 """
+import os
+
 import torch
 
 from hanabi_hip import _capi as K
@@ -59,6 +61,18 @@ class FusedLearner:
         self.eff = [(self.w1cat[:, :H], self.b1cat[:H]), (self.w2st[0], self.b2st[0])]
         self.trg = [(self.w1cat[:, H:], self.b1cat[H:]), (self.w2st[1], self.b2st[1])]
         self.H = H
+        # "thin" forward (bf16): the two dense layers on hb_thin_gemm, a kernel small enough to run on the CUs WHILE the other
+        # seat's actor GEMMs hold them (a library GEMM would wait for those to retire). It reads the weights TRANSPOSED
+        # (k-contiguous): copies kept current by one hb_actor_pack_weights launch after every optimizer step / target sync.
+        self.thin = (self.cd == torch.bfloat16 and os.environ.get("HB_THIN_LEARNER", "1") != "0" and self.Kp % 32 == 0
+                     and H % 64 == 0 and self.Np % 16 == 0 and (2 * B) % 32 == 0)
+        if self.thin:
+            self.w1catT = torch.zeros(2 * H, self.Kp, dtype=self.cd, device=dev)
+            self.w2stT = torch.zeros(2, self.Np, H, dtype=self.cd, device=dev)
+            self._hcat = torch.zeros(2 * B, 2 * H, dtype=self.cd, device=dev)
+            self._logits = torch.zeros(2, 2 * B, self.Np, dtype=self.cd, device=dev)
+            self._bias_sink = torch.zeros(max(2 * H, self.Np), **f32)   # (the transposer also converts a bias: unused here)
+            self._t_jobs = [None, None]
         # flat gradient buffer [dW1 | db1 | dW2 | db2] (fp32), one all-reduce bucket
         sizes = [layers[0].w.numel(), H, layers[1].w.numel(), AK]
         self.flat_grad = torch.zeros(sum(sizes), **f32)
@@ -133,11 +147,27 @@ class FusedLearner:
         dst_w[:w.shape[0], :w.shape[1]].copy_(w)
         dst_b[:b.shape[0]].copy_(b)
 
+    def _transpose(self, which):
+        """thin forward: refresh the transposed copies of the online (0) or target (1) weights: one launch."""
+        jobs = self._t_jobs[which]
+        if jobs is None:
+            H = self.H
+            (w1, b1), (w2, b2) = (self.eff, self.trg)[which]
+            jobs = (K.HbPackJob * 2)()
+            for j, (w, b, wt, k_rows, n_cols, kp) in enumerate(((w1, b1, self.w1catT[which * H:(which + 1) * H], self.Kp, H, self.Kp),
+                                                                (w2, b2, self.w2stT[which], H, self.Np, H))):
+                jobs[j].w, jobs[j].bias, jobs[j].wt, jobs[j].bias_out = w.data_ptr(), b.data_ptr(), wt.data_ptr(), self._bias_sink.data_ptr()
+                jobs[j].k_rows, jobs[j].n_cols, jobs[j].w_ld, jobs[j].group_cols, jobs[j].k_pad = k_rows, n_cols, w.stride(0), 0, kp
+            self._t_jobs[which] = jobs
+        K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))
+
     @torch.no_grad()
     def refresh_effective(self):
         for (w_e, b_e), l in zip(self.eff, self.layers):
             self._store(w_e, b_e, *l.effective())
         self.actor_stale = True
+        if self.thin:
+            self._transpose(0)
 
     def pack_actor(self):
         """Refresh the actor's transposed weight copies if the effective weights changed since the last call. Runs on
@@ -179,6 +209,8 @@ class FusedLearner:
     def refresh_target(self):
         for (w_t, b_t), l in zip(self.trg, self.agent.target.layers):
             self._store(w_t, b_t, *l.effective())
+        if self.thin:
+            self._transpose(1)
 
     # ---- the two halves of an update ----------------------------------------------------------------------
     def sample_and_gather(self, seed):
@@ -225,8 +257,18 @@ class FusedLearner:
                            buf.capacity, int(buf.rows_per_insert or 1), K.dptr(buf._size_wp), s))
         H = self.H
         w2 = self.eff[1][0]
-        hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
-        logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy
+        if self.thin:
+            hcat, logits = self._hcat, self._logits
+            # the transposed online weights are refreshed HERE (not right after Adam): the acting stream does not wait for
+            # it, and like the two GEMMs below the small transposer runs beside the other seat's policy GEMMs
+            self._transpose(0)
+            K.check(L.hb_thin_gemm(K.dptr(self.x), K.dptr(self.w1catT), K.dptr(self.b1cat), K.dptr(hcat), 2 * B, 2 * H, self.Kp,
+                                   self.Kp, self.Kp, 2 * H, 1, 0, 0, 0, 1, s))                       # bias + ReLU, [2B, 2H]
+            K.check(L.hb_thin_gemm(K.dptr(hcat), K.dptr(self.w2stT), None, K.dptr(logits), 2 * B, self.Np, H, 2 * H, H, self.Np,
+                                   2, H, self.Np * H, 2 * B * self.Np, 0, s))                        # {online, target}: [2, 2B, Np]
+        else:
+            hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
+            logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy
         logits_on, logits_t = logits[0], logits[1, B:]                                   # online on all 2B rows, target on obs_t
         hb, xb = hcat[:B, :H], self.x[:B]
         if self.sparse_backward:

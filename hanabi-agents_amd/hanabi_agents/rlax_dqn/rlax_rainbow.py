@@ -823,6 +823,9 @@ class DQNAgent:
         self._eff_cache = None
         if self._fv is not None:
             self._fv.refresh_all()
+        if self._fl is not None and self._fl.thin:   # the transposed weight copies follow the restored operands
+            self._fl._transpose(0)
+            self._fl._transpose(1)
         if self._fl is not None and not self.actor_lag:   # (actor_lag: the warm-up updates never touch the actor's weight sets)
             self._fl.actor_stale = True
 
@@ -1020,6 +1023,9 @@ class DQNAgent:
                 for dst, src in zip([t for pair in fl.trg for t in pair], f["trg"]):
                     dst.copy_(src)
                 fl.actor_stale = True
+                if fl.thin:
+                    fl._transpose(0)
+                    fl._transpose(1)
                 if self.actor_lag:
                     if "actor_sets" not in f:
                         raise ValueError("checkpoint was written with actor_lag=0")

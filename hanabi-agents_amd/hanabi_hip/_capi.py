@@ -132,6 +132,7 @@ SIGNATURES = {
     "hb_replay_gather_packed": (C.c_int, [_P] * 6 + [_I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, C.c_float, _I64, _I64, _P, _P]),
     "hb_c51_loss_grad": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "hb_c51_loss_sparse": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "hb_thin_gemm": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P]),
     "hb_dqn_loss_sparse": (C.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "hb_c51_backward": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
     "hb_colsum": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),

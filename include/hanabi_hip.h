@@ -419,6 +419,16 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
                        int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev, float* update_counter_dev,
                        const void* bias_online_dev, const void* bias_target_dev, void* stream);
 
+/* hb_thin_gemm: out[b][m, n] = act(sum_k x[b][m, k] * wt[b][n, k] + bias[n]) in bf16 with fp32 accumulation, both operands
+ * k-contiguous (wt is the TRANSPOSED weight matrix, as hb_actor_pack_weights writes it), as a kernel small enough (one
+ * wavefront per workgroup, 36 VGPRs, no LDS) to run on the CUs WHILE hb_actor_hidden / hb_actor_q hold them: the dense layers
+ * of DQNLearning.update_q's forward pass (rlax_rainbow.py:172-185 over noisy_mlp.py:176-185) then proceed during the other
+ * seat's policy forward instead of queueing behind it. m % 32 == 0, n % 16 == 0, k % 32 == 0; batch >= 1 with element strides;
+ * bias (bf16, may be NULL) and ReLU are applied before the bf16 rounding, like a library GEMM epilogue.                      */
+int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
+                 int32_t ldx, int32_t ldw, int32_t ldo, int32_t batch, int64_t x_batch_stride, int64_t w_batch_stride,
+                 int64_t out_batch_stride, int32_t relu, void* stream);
+
 /* hb_dqn_loss_sparse: the scalar double-Q loss of the older agent (hanabi_agents/rlax_dqn/rlax_dqn.py:170-205: td = r + g * (1 -
  * terminal) * q_target(s')[argmax q_online(s')] - q_online(s)[a], loss = mean(w_IS * 0.5 * td^2)) on precomputed q values, in the
  * same compact-gradient form as hb_c51_loss_sparse: q_online_dev [2B, row_stride] (rows 0..B-1: obs_tm1, B..2B-1: obs_t),

@@ -701,3 +701,33 @@ def test_fused_vanilla_learner_equals_autograd_learner(dtype):
                     list(plain.online.parameters()) + list(plain.target.parameters())):
         assert float((p - q).abs().max()) <= tol["w"] + 1e-3 * float(q.abs().max())
         assert float((p - q).abs().mean()) <= 0.05 * tol["w"] + 1e-6     # ... and on average they agree far better
+
+
+@pytest.mark.parametrize("m,n,k,batch,relu", [(512, 1024, 704, 1, True), (512, 1024, 512, 2, False), (64, 48, 1280, 1, True),
+                                              (512, 2496, 512, 2, False)])
+def test_thin_gemm_equals_fp32_reference(m, n, k, batch, relu):
+    """hb_thin_gemm (the learner's co-resident forward GEMM: one wavefront per 32 x 16 tile, fragments straight from global memory)
+    against an fp32 product of the same bf16 operands: equal up to the bf16 rounding of the output; strided batches (the
+    {online, target} pair reads the two halves of one activation matrix), bias + ReLU epilogue."""
+    import torch
+
+    from hanabi_hip import _capi as K
+
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    ldx = batch * k                                       # batch b reads columns [b*k, (b+1)*k) of ONE row-major matrix
+    x = (torch.randn(m, ldx, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    wt = (torch.randn(batch, n, k, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(n, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    out = torch.full((batch, m, n), 7.0, dtype=torch.bfloat16, device="cuda")
+    K.check(K.lib().hb_thin_gemm(K.dptr(x), K.dptr(wt), K.dptr(bias) if relu else None, K.dptr(out), m, n, k, ldx, k, n, batch, k, n * k,
+                                 m * n, 1 if relu else 0, K.current_stream()))
+    torch.cuda.synchronize()
+    for b in range(batch):
+        ref = x[:, b * k:(b + 1) * k].float() @ wt[b].float().t()
+        if relu:
+            ref = torch.relu(ref + bias.float())
+        err = (out[b].float() - ref).abs()
+        assert float(err.max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-3, (b, float(err.max()))
+        assert torch.equal(out[b], ref.to(torch.bfloat16)) or float((out[b] != ref.to(torch.bfloat16)).float().mean()) < 0.02
+    with pytest.raises(K.HbError):
+        K.check(K.lib().hb_thin_gemm(K.dptr(x), K.dptr(wt), None, K.dptr(out), m + 1, n, k, ldx, k, n, 1, 0, 0, 0, 0, K.current_stream()))
