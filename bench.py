@@ -536,7 +536,9 @@ def main():
                                          "(DQNLearning.loss + Adam; DQNPolicy.q_values)", test="tests/test_dtype_parity.py")
     if (session is not None and not args.vanilla and args.actor_lag == 0 and args.compute_dtype == "bfloat16"
             and not args.no_async_variant and env.packed):
-        line["async_actor"] = async_variant(args, rank, world, device, n)   # (every rank: it holds collectives)
+        session.flush()
+        line["async_actor"] = async_variant(args, rank, world, device, n,   # (every rank: it holds collectives)
+                                            streams=list(dict.fromkeys(session._lstreams.values())))
     if rank == 0 and not args.no_cpu_baseline:
         note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)   # progress on stderr; stdout carries the ONE JSON line
         note(f"timed region done ({dt / args.steps * 1e3:.4f} ms per step); timing the CPU baselines on rank 0")
@@ -557,7 +559,7 @@ def main():
         dist.destroy_process_group()
 
 
-def async_variant(args, rank, world, device, n):
+def async_variant(args, rank, world, device, n, streams=None):
     """The same workload with the asynchronous actor (RlaxRainbowParams.actor_lag = 1, one learner stream per
     agent), timed with the same protocol as the headline. Reported BESIDE the headline, which keeps the reference's
     synchronous semantics: here the policy acts on weights that are one update old (tests/test_async_actor.py)."""
@@ -579,8 +581,12 @@ def async_variant(args, rank, world, device, n):
             for t in list(a.online.parameters()) + list(a.online.buffers()):
                 dist.broadcast(t.data, 0)
             a.target.load_state_dict(a.online.state_dict())
-    session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_priority=args.learner_priority,
-                              stream_per_agent=True)
+    # the learner streams of the headline session are reused: which HIP hardware queue a stream lands on changes the step time
+    # by up to 3x, and the headline's streams are the ones whose placement has just been measured
+    pool = iter(streams or [])
+    factory = (lambda: next(pool, None) or torch.cuda.Stream(device=device, priority=args.learner_priority)) if streams else True
+    session = SelfPlaySession(env, agents, updates_per_step=args.updates_per_step, learner_stream=factory,
+                              learner_priority=args.learner_priority, stream_per_agent=True)
     for _ in range(args.prime + args.warmup):
         session.step()
     session.flush()
