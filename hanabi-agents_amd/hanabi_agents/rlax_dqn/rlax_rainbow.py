@@ -987,7 +987,7 @@ class DQNAgent:
                                eff=[t.cpu() for pair in fl.eff for t in pair], trg=[t.cpu() for pair in fl.trg for t in pair])
             if self.actor_lag:   # the set the policy reads is one update behind `eff`: it is state of its own
                 fl.pack_actor()
-                sd["fused"]["actor_sets"] = [t.cpu() for st in fl.actor.sets for t in st]
+                sd["fused"]["actor_sets"] = [t.cpu() for t in fl.actor.state_tensors()]
                 sd["fused"]["n_packed"] = fl.n_packed
                 sd["pending_fills"] = [list(x) for x in self._pending_fills]
         else:
@@ -1029,7 +1029,7 @@ class DQNAgent:
                 if self.actor_lag:
                     if "actor_sets" not in f:
                         raise ValueError("checkpoint was written with actor_lag=0")
-                    for dst, src in zip([t for st in fl.actor.sets for t in st], f["actor_sets"]):
+                    for dst, src in zip(fl.actor.state_tensors(), f["actor_sets"]):
                         dst.copy_(src)
                     fl.n_packed, fl.packed_ev, fl.actor_stale = int(f["n_packed"]), [None, None], False
                     self._pending_fills = [tuple(x) for x in sd.get("pending_fills", [])]

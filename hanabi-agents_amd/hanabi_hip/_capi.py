@@ -146,6 +146,10 @@ SIGNATURES = {
     "hb_actor_q_select": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P, C.c_float, _U64, _U64, _I64, _P, _P, _P]),
     "hb_actor_act": (C.c_int, [_P, _I32, _P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _P, C.c_float, _U64, _U64, _I64,
                                _P, _P, _P]),
+    "hb_actor_fused_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "hb_actor_fused_sizes": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I32)]),
+    "hb_actor_fused_pack": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hb_actor_fused_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }

@@ -1,4 +1,7 @@
 """Thin wrappers over the actor and replay-insert kernels (hb_policy_act, hb_actor_*, hb_replay_insert)."""
+import ctypes
+import os
+
 import torch
 
 from . import _capi as K
@@ -84,6 +87,21 @@ class ActorMFMA:
         # tail, which delays the GEMM's second round of workgroups), so the separate hb_policy_select launch stays the default
         self.fuse_select = False
         self._set_ptrs = [tuple(t.data_ptr() for t in st) for st in self.sets]
+        # Round 3: the whole forward as ONE kernel (csrc/actor_fused.hip) for bit-packed observations on the reference topology
+        # (hidden 512, 51 atoms): its own fragment-major weight copies per set. HB_ACTOR_FUSED=0 keeps the two-kernel form.
+        self.fused = bool(K.lib().hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) and os.environ.get("HB_ACTOR_FUSED", "1") != "0"
+        self.fsets = []
+        if self.fused:
+            b1, b2, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+            K.check(K.lib().hb_actor_fused_sizes(obs_len, hidden, n_actions, n_atoms, ctypes.byref(b1), ctypes.byref(b2), ctypes.byref(nb)))
+            self.fsets = [(torch.zeros(b1.value // 2, **bf), torch.zeros(hidden, dtype=torch.float32, device=device),
+                           torch.zeros(b2.value // 2, **bf), torch.zeros(nb.value, dtype=torch.float32, device=device))
+                          for _ in range(self.n_sets)]
+        self._fset_ptrs = [tuple(t.data_ptr() for t in st) for st in self.fsets]
+
+    def state_tensors(self):
+        """Every packed weight copy of every set (checkpoints: with actor_lag the acting set is state of its own)."""
+        return [t for st in self.sets for t in st] + [t for st in self.fsets for t in st]
 
     @staticmethod
     def supports(obs_len, hidden, n_atoms, k_pad, dtype):
@@ -106,6 +124,11 @@ class ActorMFMA:
             if len(self._jobs) < 16:
                 self._jobs[key] = jobs
         K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))   # both layers in one launch
+        if self.fused:
+            f = self._fset_ptrs[s]
+            K.check(K.lib().hb_actor_fused_pack(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+                                                self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
+                                                K.current_stream()))
 
     def q_values(self, obs, support, s=0):
         """The two GEMMs of a policy call without the selection: q [N, A] fp32 (persistent buffer). For callers that fuse the
@@ -126,8 +149,13 @@ class ActorMFMA:
             c = self._q_call = (obs.data_ptr(), n, L.hb_actor_hidden_packed if packed else L.hb_actor_hidden, L.hb_actor_q,
                                 self.h.data_ptr(), self.q.data_ptr(), support.data_ptr())
         _, n, hidden, qfn, hp, qp, sp = c
-        w1p, b1p, w2p, b2p = self._set_ptrs[s]
         st = K.current_stream()
+        if self.fused and obs.dtype == torch.int32:
+            f = self._fset_ptrs[s]
+            K.check(K.lib().hb_actor_fused_q(c[0], n, self.obs_len, f[0], f[1], f[2], f[3], sp, self.hidden, self.n_actions,
+                                             self.n_atoms, qp, st))
+            return self.q
+        w1p, b1p, w2p, b2p = self._set_ptrs[s]
         K.check(hidden(c[0], n, self.obs_len, w1p, self.k_pad, b1p, self.hidden, hp, st))
         K.check(qfn(hp, n, self.hidden, w2p, b2p, sp, self.n_actions, self.n_atoms, qp, st))
         return self.q
@@ -143,6 +171,14 @@ class ActorMFMA:
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
             self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
         actions = torch.empty(n, dtype=torch.int32, device=obs.device)
+        if self.fused and packed:
+            f = self._fset_ptrs[s]
+            st = K.current_stream()
+            K.check(K.lib().hb_actor_fused_q(obs.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3], support.data_ptr(), self.hidden,
+                                             self.n_actions, self.n_atoms, self.q.data_ptr(), st))
+            K.check(K.lib().hb_policy_select(self.q.data_ptr(), legal.data_ptr(), n, self.n_actions, float(epsilon), int(seed),
+                                             int(draw), int(first_game_id), actions.data_ptr(), st))
+            return actions
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
         K.check(K.lib().hb_actor_act(obs.data_ptr(), 1 if packed else 0, legal.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p,
                                      self.hidden, self.h.data_ptr(), w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,

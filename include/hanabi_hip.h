@@ -541,6 +541,25 @@ int hb_actor_act(const void* obs_dev, int32_t obs_is_packed, const int8_t* legal
                  const float* b2_dev, const float* support_dev, int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon,
                  uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, uint32_t* tickets_dev, void* stream);
 
+/* ---- The whole policy forward as ONE kernel (csrc/actor_fused.hip, round 3): bit-packed observation rows -> q values, the
+ * hidden activations never leave the CU and the logits are never rounded (fp32 accumulators -> C51 expectation).
+ * Replaces DQNPolicy's forward (hanabi_agents/rlax_dqn/rlax_rainbow.py:113-122 over noisy_mlp.py:176-185) for the reference
+ * topology layers=[512], n_atoms=51 (params.py:13,18); other shapes use hb_actor_hidden[_packed] + hb_actor_q.
+ *   hb_actor_fused_supported  1 when the shape is covered (hidden == 512, n_atoms == 51, n_actions <= 80, obs_len <= 4096)
+ *   hb_actor_fused_sizes      bytes of the two fragment-major weight copies and floats of the physical-order output bias
+ *   hb_actor_fused_pack       effective weights (bf16 row-major W1 [>= obs_len, 512] / W2 [512, >= A * 51], bf16 biases) -> the
+ *                             copies the kernel streams: one launch; call after every weight change
+ *   hb_actor_fused_q          q [n_rows, n_actions] fp32 from obs_bits [n_rows, ceil(obs_len / 32)] u32                      */
+int hb_actor_fused_supported(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms);
+int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, int64_t* w1f_bytes,
+                         int64_t* w2f_bytes, int32_t* b2f_floats);
+int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld,
+                        const void* b2_dev, int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev,
+                        float* b1f_dev, void* w2f_dev, float* b2f_dev, void* stream);
+int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                     const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                     int32_t n_atoms, float* q_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
