@@ -45,8 +45,8 @@ constexpr int FK = 51;                  // atoms (params.py:18)
 constexpr int S2 = FH / 32;             // K steps of layer 2
 constexpr int LUT_BYTES = 65536;        // 256 byte values x 16 slots x 16 B
 constexpr int H_BYTES = FM * FH * 2;    // 131 072
-constexpr int FRAG_BYTES = 8 * FM * 16; // one buffer of quarter-action triples: [wave][row] float4
-constexpr int LDS_TOTAL = H_BYTES + 2 * FRAG_BYTES;   // 163 840 = all of a CU's LDS
+constexpr int FRAG_FLOATS = 3 * 8 * FM; // one buffer of quarter-action triples: [max | sum | weighted sum][wave][row] fp32 (12 KiB)
+constexpr int LDS_TOTAL = H_BYTES + 32768;            // 163 840 = all of a CU's LDS
 constexpr float NEG_BIG = -1e30f;
 
 struct FusedArgs {
@@ -61,7 +61,30 @@ struct FusedArgs {
   const float* support;    // [51]
   float* q;                // [m][n_actions]
   int n_actions, n_pass;
+  unsigned long long* stamps;   // diagnostic builds only (-DHB_STAMPS): 16 u64 per wavefront
 };
+
+// In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with -DHB_STAMPS, into the separate diagnostic
+// library (make stamps); the shipped kernel contains none of this.
+#ifdef HB_STAMPS
+#define HB_FSTAMP(slot)                                                                              \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    unsigned long long hb_t_;                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t_)::"memory");                    \
+    if (a.stamps && lane == 0) a.stamps[(static_cast<long long>(blockIdx.x) * 8 + wave) * 16 + (slot)] = hb_t_; \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
+#define HB_FSTAMP_REAL(slot)                                                                         \
+  do {                                                                                               \
+    unsigned long long hb_t_;                                                                        \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t_)::"memory");                \
+    if (a.stamps && lane == 0) a.stamps[(static_cast<long long>(blockIdx.x) * 8 + wave) * 16 + (slot)] = hb_t_; \
+  } while (0)
+#else
+#define HB_FSTAMP(slot) do {} while (0)
+#define HB_FSTAMP_REAL(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
@@ -78,8 +101,23 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
   c.u = v;
   return c.f;
 }
-__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Reductions over the four 16-lane groups of a wavefront (lanes l, l ^ 16, l ^ 32, l ^ 48) use gfx950's row swaps, VALU only:
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper
+// half of the first with the lower half of the second; called with the same value twice they return {x[row & ~1], x[row | 1]}
+// and {x[lower], x[upper]} (HB_SWAP16 / HB_SWAP32 in the epilogue). Every lane ends with the full result.
+// v_max_f32 / v_max3_f32 as they are: fmaxf() makes hipcc quiet possible signalling NaNs first (one v_max x, x, x per operand)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
@@ -88,28 +126,41 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
   const int r = lane & 15, qd = lane >> 4;
   const long long row0 = static_cast<long long>(blockIdx.x) * FM;
   const int s1 = a.s1, G = (s1 + 3) >> 2;
-  unsigned char* bits = lds + LUT_BYTES;   // [8 m][G][64 lanes] u32: byte i of the word = byte (4 (4 g + i) + q) of row 16 m + r
+  // Table and bit rows sit at the TOP of the LDS (over the quarter-triple buffers and the last rows of H), so that after layer 1
+  // a wavefront can write the first m_early row tiles of H while other wavefronts are still reading them.
+  unsigned char* lutb = lds + (LDS_TOTAL - LUT_BYTES);
+  const int bits_off = LDS_TOTAL - LUT_BYTES - 2048 * G;
+  unsigned char* bits = lds + bits_off;   // [8 m][G][64 lanes] u32: byte i of the word = byte (4 (4 g + i) + q) of row 16 m + r
+  const int m_early = bits_off >> 14;     // row tiles (16 rows x 1 KiB) below the bit rows
 
+  HB_FSTAMP_REAL(14);
+  HB_FSTAMP(0);
   // ---- first weights in flight before anything else
   const uint4* w1p = a.w1f + (4 * wave) * 64 + lane;   // step s: + s * 2048; n-tile n of this wavefront: + n * 64
   uint4 wa[4], wb[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) wa[n] = w1p[n * 64];
 
-  // ---- table: entry (v, slot) at v * 256 + slot * 16
-  for (int e = tid; e < 4096; e += FNT) {
-    const uint32_t v = static_cast<uint32_t>(e) >> 4;
-    *reinterpret_cast<uint4*>(lds + e * 16) = make_uint4(bits2_bf16(v, 0), bits2_bf16(v, 1), bits2_bf16(v, 2), bits2_bf16(v, 3));
-  }
-  // ---- observation bits, byte-transposed so that a lane finds the bytes of four consecutive K steps in one dword
-  for (int it = tid; it < FM * G; it += FNT) {
+  // ---- observation bits, byte-transposed so that a lane finds the bytes of four consecutive K steps in one dword; the first
+  // item's loads (HBM latency) are in flight while the table is built
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  auto load_item = [&](int it) {
     const int rr = it & (FM - 1), g = it >> 7;
     long long row = row0 + rr;
     if (row >= a.m) row = a.m - 1;   // rows past the end are computed and dropped
     const uint32_t* src = a.obs + row * a.words + 4 * g;
-    uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (4 * g + i < a.words) ? src[i] : 0u;
+  };
+  if (tid < FM * G) load_item(tid);
+  // ---- table: entry (v, slot) at v * 256 + slot * 16
+  for (int e = tid; e < 4096; e += FNT) {
+    const uint32_t v = static_cast<uint32_t>(e) >> 4;
+    *reinterpret_cast<uint4*>(lutb + e * 16) = make_uint4(bits2_bf16(v, 0), bits2_bf16(v, 1), bits2_bf16(v, 2), bits2_bf16(v, 3));
+  }
+  for (int it = tid; it < FM * G; it += FNT) {
+    const int rr = it & (FM - 1), g = it >> 7;
+    if (it != tid) load_item(it);
     uint32_t* dst = reinterpret_cast<uint32_t*>(bits) + (static_cast<size_t>((rr >> 4) * G + g) * 64 + (rr & 15));
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -118,17 +169,21 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
       dst[qq * 16] = o;
     }
   }
+  HB_FSTAMP(1);
   __syncthreads();
+  HB_FSTAMP(2);
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][8];   // accumulators start at the bias of their 4 columns
 #pragma unroll
-  for (int n = 0; n < 4; ++n)
+  for (int n = 0; n < 4; ++n) {
+    const float4 b = *reinterpret_cast<const float4*>(a.b1 + 64 * wave + 16 * n + 4 * qd);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{b.x, b.y, b.z, b.w};
+  }
 
   // =========================== layer 1: H[128 rows][64 wave + 0..63] over K = 32 s1
   {
-    const unsigned char* lut = lds + r * 16;
+    const unsigned char* lut = lutb + r * 16;
     const uint32_t* bw = reinterpret_cast<const uint32_t*>(bits) + lane;
 #define HB_L1_STEP(I, WCUR, WNXT, HAVE_NEXT)                                                                   \
   {                                                                                                            \
@@ -162,55 +217,65 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     }
 #undef HB_L1_STEP
   }
+  HB_FSTAMP(3);
 
   // first weights of layer 2 in flight across the barrier and the H write
   const uint4* w2p = a.w2f + (4 * wave) * 64 + lane;   // pass p: + p * S2 * 2048; step s: + s * 2048
 #pragma unroll
   for (int n = 0; n < 4; ++n) wa[n] = w2p[n * 64];
 
-  __syncthreads();   // every wavefront has finished reading the table and the bit rows: H may overlay them
-
-  // ---- H = relu(acc + b1) as bf16: acc[n][m][j] = row 16 m + r, unit 64 wave + 16 n + 4 q + j; 8-byte LDS writes
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const float4 b = *reinterpret_cast<const float4*>(a.b1 + 64 * wave + 16 * n + 4 * qd);
-    const int chunk = 8 * wave + 2 * n + (qd >> 1);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const float v0 = fmaxf(acc[n][m][0] + b.x, 0.f), v1 = fmaxf(acc[n][m][1] + b.y, 0.f);
-      const float v2 = fmaxf(acc[n][m][2] + b.z, 0.f), v3 = fmaxf(acc[n][m][3] + b.w, 0.f);
-      *reinterpret_cast<uint2*>(lds + (16 * m + r) * 1024 + ((chunk ^ r) << 4) + (qd & 1) * 8) =
-          make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
-    }
+  // ---- H = relu(acc) as bf16: acc[n][m][j] = row 16 m + r, unit 64 wave + 16 n + 4 q + j; 8-byte LDS writes. Row tiles below the
+  // bit rows first; the others once every wavefront has finished reading the table and the bit rows.
+#define HB_H_WRITE(COND)                                                                                        \
+  _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                               \
+    if (COND) {                                                                                                 \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                           \
+        const int chunk = 8 * wave + 2 * n + (qd >> 1);                                                         \
+        const float v0 = fmaxf(acc[n][m][0], 0.f), v1 = fmaxf(acc[n][m][1], 0.f);                               \
+        const float v2 = fmaxf(acc[n][m][2], 0.f), v3 = fmaxf(acc[n][m][3], 0.f);                               \
+        *reinterpret_cast<uint2*>(lds + (16 * m + r) * 1024 + ((chunk ^ r) << 4) + (qd & 1) * 8) =              \
+            make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));                                                   \
+      }                                                                                                         \
+    }                                                                                                           \
   }
+  HB_H_WRITE(m < m_early)
+  HB_FSTAMP(4);
   __syncthreads();
+  HB_H_WRITE(m >= m_early)
+#undef HB_H_WRITE
+
+  HB_FSTAMP(5);
+  __syncthreads();
+  HB_FSTAMP(6);
 
   // =========================== layer 2 in passes of 512 physical columns + the C51 expectation from the accumulators
   const int n_pass = a.n_pass, A = a.n_actions;
   const int full_cap = 8 * n_pass;
-  // per-lane support values: whole action: atom 4 i + q (i < 12), atom 48 + q (the 13th register, lanes q < 3)
-  float supF[13];
+  // per-lane support values, in the register pairs the packed sums use. Whole action: register (n, j), n < 3, holds atom
+  // 4 (4 n + j) + q; register (3, 0) holds atom 48 + q in lanes q < 3. Quarter f: registers (3, 1..3) hold atom 13 f + 4 (j - 1) + q,
+  // register (3, 0) of lanes q == 3 atom 13 f + 12.
+  auto sup_at = [&](int k) { return a.support[k < FK ? k : FK - 1]; };
+  f32x2 supF[6];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) {
-    const int k = 4 * i + qd;
-    supF[i] = a.support[k < FK ? k : FK - 1];
-  }
+  for (int i = 0; i < 6; ++i) supF[i] = f32x2{sup_at(4 * (2 * i) + qd), sup_at(4 * (2 * i + 1) + qd)};
+  const float supF12 = sup_at(48 + qd);
   const int fq = wave & 3;   // which quarter of its extra action this wavefront holds
-  float supZ[4];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int k = 13 * fq + 4 * i + qd;
-    supZ[i] = a.support[k < FK ? k : FK - 1];
-  }
-  supZ[3] = a.support[13 * fq + 12 < FK ? 13 * fq + 12 : FK - 1];
+  const f32x2 supZa = f32x2{sup_at(13 * fq + qd), sup_at(13 * fq + 4 + qd)};
+  const f32x2 supZb = f32x2{sup_at(13 * fq + 8 + qd), sup_at(13 * fq + 12)};
   constexpr float LOG2E = 1.44269504088896340736f;
   const unsigned char* hrow = lds + r * 1024;
 
   for (int p = 0; p < n_pass; ++p) {
+    const int slot = 8 * p + wave;
+    {   // accumulators start at the bias (physical column order; NEG_BIG on unused columns, whose weights are zero)
+      const float* bp = a.b2 + static_cast<long long>(slot) * 64 + 4 * qd;
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 4; ++n) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * n);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{b.x, b.y, b.z, b.w};
+      }
+    }
     const uint4* wp = w2p + static_cast<long long>(p) * S2 * 2048;
 #define HB_L2_STEP(S, WCUR, WNXT, HAVE_NEXT)                                                                   \
   {                                                                                                            \
@@ -233,6 +298,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
       HB_L2_STEP(s + 1, wb, wa, (s + 2 < S2))
     }
 #undef HB_L2_STEP
+    if (p < 2) HB_FSTAMP(7 + 3 * p);
     // next pass's first weights in flight during the epilogue
     if (p + 1 < n_pass) {
 #pragma unroll
@@ -240,85 +306,148 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     }
 
     // ---- epilogue of slot (p, wave): register (n, j) of lane group q is physical column 16 n + 4 q + j of the slot
-    const int slot = 8 * p + wave;
-    const float* bp = a.b2 + static_cast<long long>(slot) * 64 + 4 * qd;
-    float4 bias[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) bias[n] = *reinterpret_cast<const float4*>(bp + 16 * n);
     const bool full_ok = slot < A && slot < full_cap;
-    float4* fb = reinterpret_cast<float4*>(lds + H_BYTES + (p & 1) * FRAG_BYTES) + wave * FM;
+    float* fb = reinterpret_cast<float*>(lds + H_BYTES) + (p & 1) * FRAG_FLOATS + wave * FM;   // component c: + c * 8 * FM
+    // Written STAGE BY STAGE over the 8 row tiles (m is the inner loop everywhere): a wavefront issues in order, and one row
+    // tile's softmax is a single dependent chain (max -> swaps -> exp -> sums -> swaps), so consecutive instructions must come
+    // from different row tiles to keep the vector pipe busy (row tile after row tile: 9.6 k cycles per pass; see DESIGN).
+    const f32x2 L2 = f32x2{LOG2E, LOG2E};
+    float qF[8], zm[8], zs[8], zt[8], vf12[8], vz3[8], nmx[8], nmz[8];
+#define HB_M for (int m = 0; m < 8; ++m)
+#define HB_SWAP16(X, OP) { const u32x2 t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(X), __float_as_uint(X), false, false); \
+                           X = OP(__uint_as_float(t_.x), __uint_as_float(t_.y)); }
+#define HB_SWAP32(X, OP) { const u32x2 t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false); \
+                           X = OP(__uint_as_float(t_.x), __uint_as_float(t_.y)); }
+#define HB_ADD(A_, B_) ((A_) + (B_))
+    // register (3, 0) is shared: lanes q < 3 -> atoms 48..50 of the whole action, lanes q == 3 -> the quarter's 13th position
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      float x[16];
+    HB_M { vf12[m] = qd < 3 ? acc[3][m][0] : NEG_BIG; vz3[m] = qd == 3 ? acc[3][m][0] : NEG_BIG; }
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        x[4 * n + 0] = (acc[n][m][0] + bias[n].x) * LOG2E;
-        x[4 * n + 1] = (acc[n][m][1] + bias[n].y) * LOG2E;
-        x[4 * n + 2] = (acc[n][m][2] + bias[n].z) * LOG2E;
-        x[4 * n + 3] = (acc[n][m][3] + bias[n].w) * LOG2E;
-      }
-      // register 12 is shared: lanes q < 3 -> atoms 48..50 of the whole action, lanes q == 3 -> the quarter's 13th position
-      const float xf12 = qd < 3 ? x[12] : NEG_BIG * LOG2E;
-      const float xz3 = qd == 3 ? x[12] : NEG_BIG * LOG2E;
-      // whole action
-      float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+    HB_M nmx[m] = vmax3(acc[0][m][0], acc[0][m][1], acc[0][m][2]);
 #pragma unroll
-      for (int i = 4; i < 12; ++i) mx = fmaxf(mx, x[i]);
-      mx = fmaxf(mx, xf12);
-      float mz = fmaxf(fmaxf(x[13], x[14]), fmaxf(x[15], xz3));
-      mx = fmaxf(mx, xor16(mx));
-      mz = fmaxf(mz, xor16(mz));
-      mx = fmaxf(mx, xor32(mx));
-      mz = fmaxf(mz, xor32(mz));
-      float sF = 0.f, tF = 0.f;
+    HB_M nmx[m] = vmax3(nmx[m], acc[0][m][3], acc[1][m][0]);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const float e = exp2_fast(x[i] - mx);
-        sF += e;
-        tF += e * supF[i];
-      }
-      {
-        const float e = exp2_fast(xf12 - mx);
-        sF += e;
-        tF += e * supF[12];
-      }
-      float sZ = 0.f, tZ = 0.f;
+    HB_M nmx[m] = vmax3(nmx[m], acc[1][m][1], acc[1][m][2]);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float e = exp2_fast(x[13 + i] - mz);
-        sZ += e;
-        tZ += e * supZ[i];
-      }
-      {
-        const float e = exp2_fast(xz3 - mz);
-        sZ += e;
-        tZ += e * supZ[3];
-      }
-      sF += xor16(sF); tF += xor16(tF); sZ += xor16(sZ); tZ += xor16(tZ);
-      sF += xor32(sF); tF += xor32(tF); sZ += xor32(sZ); tZ += xor32(tZ);
-      if (qd == 0) {
+    HB_M nmx[m] = vmax3(nmx[m], acc[1][m][3], acc[2][m][0]);
+#pragma unroll
+    HB_M nmx[m] = vmax3(nmx[m], acc[2][m][1], acc[2][m][2]);
+#pragma unroll
+    HB_M nmx[m] = vmax3(nmx[m], acc[2][m][3], vf12[m]);
+#pragma unroll
+    HB_M nmz[m] = vmax(vmax3(acc[3][m][1], acc[3][m][2], acc[3][m][3]), vz3[m]);
+#pragma unroll
+    HB_M HB_SWAP16(nmx[m], vmax)
+#pragma unroll
+    HB_M HB_SWAP16(nmz[m], vmax)
+#pragma unroll
+    HB_M HB_SWAP32(nmx[m], vmax)
+#pragma unroll
+    HB_M HB_SWAP32(nmz[m], vmax)
+#pragma unroll
+    HB_M { nmx[m] *= -LOG2E; nmz[m] *= -LOG2E; }
+    f32x2 s2[8], t2[8];
+#define HB_PAIR_FIRST(N, LO, SUP)                                                                   \
+  _Pragma("unroll") HB_M {                                                                          \
+    const f32x2 arg = f32x2{acc[N][m][LO], acc[N][m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
+    const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};                                      \
+    s2[m] = e;                                                                                      \
+    t2[m] = e * SUP;                                                                                \
+  }
+#define HB_PAIR(N, LO, SUP)                                                                         \
+  _Pragma("unroll") HB_M {                                                                          \
+    const f32x2 arg = f32x2{acc[N][m][LO], acc[N][m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
+    const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};                                      \
+    s2[m] += e;                                                                                     \
+    t2[m] += e * SUP;                                                                               \
+  }
+    HB_PAIR_FIRST(0, 0, supF[0])
+    HB_PAIR(0, 2, supF[1])
+    HB_PAIR(1, 0, supF[2])
+    HB_PAIR(1, 2, supF[3])
+    HB_PAIR(2, 0, supF[4])
+    HB_PAIR(2, 2, supF[5])
+#undef HB_PAIR
+#undef HB_PAIR_FIRST
+    float sF[8], tF[8];
+#pragma unroll
+    HB_M {
+      const float e12 = exp2_fast(vf12[m] * LOG2E + nmx[m]);
+      sF[m] = s2[m].x + s2[m].y + e12;
+      tF[m] = t2[m].x + t2[m].y + e12 * supF12;
+    }
+    // the quarter: registers (3, 1), (3, 2) | (3, 3), shared register
+#pragma unroll
+    HB_M {
+      const f32x2 arg = f32x2{acc[3][m][1], acc[3][m][2]} * L2 + f32x2{nmz[m], nmz[m]};
+      const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};
+      s2[m] = e;
+      t2[m] = e * supZa;
+    }
+#pragma unroll
+    HB_M {
+      const f32x2 arg = f32x2{acc[3][m][3], vz3[m]} * L2 + f32x2{nmz[m], nmz[m]};
+      const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};
+      s2[m] += e;
+      t2[m] += e * supZb;
+    }
+#pragma unroll
+    HB_M { zs[m] = s2[m].x + s2[m].y; zt[m] = t2[m].x + t2[m].y; }
+#pragma unroll
+    HB_M HB_SWAP16(sF[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP16(tF[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP16(zs[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP16(zt[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP32(sF[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP32(tF[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP32(zs[m], HB_ADD)
+#pragma unroll
+    HB_M HB_SWAP32(zt[m], HB_ADD)
+#pragma unroll
+    HB_M { zm[m] = -nmz[m]; qF[m] = tF[m] * __builtin_amdgcn_rcpf(sF[m]) * (1.0f / FK); }   // (zm: the maximum in log2 units: the merge uses exp2)
+#undef HB_M
+#undef HB_SWAP16
+#undef HB_SWAP32
+#undef HB_ADD
+    if (qd == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
         const long long row = row0 + 16 * m + r;
-        if (full_ok && row < a.m) a.q[row * A + slot] = tF / sF * (1.0f / FK);
-        fb[16 * m + r] = make_float4(mz, sZ, tZ, 0.f);   // (mz is in log2 units: exp2 below)
+        if (full_ok && row < a.m) a.q[row * A + slot] = qF[m];
+        fb[16 * m + r] = zm[m];
+        fb[8 * FM + 16 * m + r] = zs[m];
+        fb[16 * FM + 16 * m + r] = zt[m];
       }
     }
+    if (p < 2) HB_FSTAMP(8 + 3 * p);
     __syncthreads();
-    // ---- the pass's two extra actions: combine their four quarters (wavefronts 4 g .. 4 g + 3)
+    // ---- the pass's two extra actions: combine their four quarters (wavefronts 4 g .. 4 g + 3). The buffer alternates with the
+    // pass parity: the next pass's barrier separates these reads from the writes of pass p + 2.
     if (tid < 2 * FM) {
       const int rr = tid & (FM - 1), g = tid >> 7;
       const int ea = full_cap + 2 * p + g;
       const long long row = row0 + rr;
       if (ea < A && row < a.m) {
-        const float4* f4 = reinterpret_cast<const float4*>(lds + H_BYTES + (p & 1) * FRAG_BYTES) + (4 * g) * FM + rr;
-        const float4 v0 = f4[0], v1 = f4[FM], v2 = f4[2 * FM], v3 = f4[3 * FM];
-        const float M = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x));
-        const float e0 = exp2_fast(v0.x - M), e1 = exp2_fast(v1.x - M), e2 = exp2_fast(v2.x - M), e3 = exp2_fast(v3.x - M);
-        const float S = v0.y * e0 + v1.y * e1 + v2.y * e2 + v3.y * e3;
-        const float T = v0.z * e0 + v1.z * e1 + v2.z * e2 + v3.z * e3;
-        a.q[row * A + ea] = T / S * (1.0f / FK);
+        const float* f = reinterpret_cast<const float*>(lds + H_BYTES) + (p & 1) * FRAG_FLOATS + (4 * g) * FM + rr;
+        const float m0 = f[0], m1 = f[FM], m2 = f[2 * FM], m3 = f[3 * FM];
+        const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float e0 = exp2_fast(m0 - M), e1 = exp2_fast(m1 - M), e2 = exp2_fast(m2 - M), e3 = exp2_fast(m3 - M);
+        const float* fs = f + 8 * FM;
+        const float* ft = f + 16 * FM;
+        const float S = fs[0] * e0 + fs[FM] * e1 + fs[2 * FM] * e2 + fs[3 * FM] * e3;
+        const float T = ft[0] * e0 + ft[FM] * e1 + ft[2 * FM] * e2 + ft[3 * FM] * e3;
+        a.q[row * A + ea] = T * __builtin_amdgcn_rcpf(S) * (1.0f / FK);
       }
     }
+    if (p < 2) HB_FSTAMP(9 + 3 * p);
   }
+  HB_FSTAMP_REAL(15);
 }
 
 // ---- packer: effective weights (bf16, row-major, possibly padded GEMM operands) -> the fragment-major copies
@@ -381,7 +510,7 @@ int passes_for(int n_actions) { return (n_actions + 9) / 10; }
 extern "C" {
 
 int hb_actor_fused_supported(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms) {
-  return obs_len >= 1 && obs_len <= 4096 && hidden == FH && n_atoms == FK && n_actions >= 1 && n_actions <= 80 ? 1 : 0;
+  return obs_len >= 1 && obs_len <= 4096 && hidden == FH && n_atoms == FK && n_actions >= 1 && n_actions <= 80 ? 1 : 0;   // (<= 32 passes)
 }
 
 int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, int64_t* w1f_bytes, int64_t* w2f_bytes,
@@ -413,9 +542,30 @@ int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, c
   return HB_OK;
 }
 
+static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                        const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream);
+
 int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                      const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions, int32_t n_atoms,
                      float* q_dev, void* stream) {
+  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
+                      nullptr, stream);
+}
+
+#ifdef HB_STAMPS
+// diagnostic library only: the same launch with per-wavefront phase stamps (16 u64 per wavefront, 8 wavefronts per 128 rows)
+int hb_actor_fused_q_stamped(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                             const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                             int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream) {
+  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
+                      stamps_dev, stream);
+}
+#endif
+
+static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                        const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream) {
   if (!obs_bits_dev || !w1f_dev || !b1f_dev || !w2f_dev || !b2f_dev || !support_dev || !q_dev) return fail(HB_ERR_INVALID, "null argument");
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
   if (n_rows <= 0) return HB_OK;
@@ -425,6 +575,7 @@ int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_l
   a.obs = obs_bits_dev; a.m = n_rows; a.words = (obs_len + 31) / 32; a.s1 = 2 * ((obs_len + 63) / 64);
   a.w1f = static_cast<const uint4*>(w1f_dev); a.b1 = b1f_dev; a.w2f = static_cast<const uint4*>(w2f_dev); a.b2 = b2f_dev;
   a.support = support_dev; a.q = q_dev; a.n_actions = n_actions; a.n_pass = passes_for(n_actions);
+  a.stamps = stamps_dev;
   const dim3 grid(static_cast<unsigned>((n_rows + FM - 1) / FM));
   hipLaunchKernelGGL(actor_fused_kernel, grid, dim3(FNT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
