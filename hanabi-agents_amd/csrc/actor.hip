@@ -28,6 +28,7 @@
 // row halves one barrier apart: 39.3 / 46.1 us) — it gives up the ds_read / MFMA interleaving inside each wavefront.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include <cstdint>
 #include <cstdlib>
@@ -81,6 +82,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) |
          (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
 }
+// The output layer's logits tile is staged in LDS as fp16 (round 3; bf16 before): same 2 bytes, 8 x finer for |x| < 65 504, and the
+// q values follow the fp32 logits 8 x more closely (tolerance.py). fp32 accumulators are clamped into the fp16 range first.
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+  const __half2 h = __floats2half2_rn(fminf(fmaxf(lo, -65000.f), 65000.f), fminf(fmaxf(hi, -65000.f), 65000.f));
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+__device__ __forceinline__ float f16_lo(uint32_t d) { return __half2float(__ushort_as_half(static_cast<unsigned short>(d & 0xFFFFu))); }
+__device__ __forceinline__ float f16_hi(uint32_t d) { return __half2float(__ushort_as_half(static_cast<unsigned short>(d >> 16))); }
 // four unsigned bytes of `d` -> four bf16 (exact for 0..255): v_cvt_f32_ubyteN + v_perm_b32
 __device__ __forceinline__ void widen4(uint32_t d, uint32_t& lo, uint32_t& hi) {
   const float f0 = static_cast<float>(d & 0xFFu), f1 = static_cast<float>((d >> 8) & 0xFFu);
@@ -89,7 +98,7 @@ __device__ __forceinline__ void widen4(uint32_t d, uint32_t& lo, uint32_t& hi) {
   hi = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
 }
 
-// C51 expectation of one (row, action): mean_k softmax(x)_k * support_k over KK bf16 logits that start LEAD
+// C51 expectation of one (row, action): mean_k softmax(x)_k * support_k over KK fp16 logits that start LEAD
 // elements past the 8-byte aligned LDS address p8 (the arithmetic of policy_kernel, policy.hip). The logits are
 // fetched with 8-byte LDS reads (rows are 520 B apart: conflict-free per 32-lane half) instead of KK 2-byte reads,
 // which made this epilogue LDS-issue-bound (22 us of a 60 us kernel).
@@ -109,7 +118,7 @@ __device__ __forceinline__ float c51_expectation(const uint2* __restrict__ p8, c
     constexpr int dummy = 0;
     (void)dummy;
     const int h = k + LEAD;
-    x[k] = (h & 1) ? __uint_as_float(d[h >> 1] & 0xFFFF0000u) : __uint_as_float(d[h >> 1] << 16);
+    x[k] = (h & 1) ? f16_hi(d[h >> 1]) : f16_lo(d[h >> 1]);
   }
   float mx = x[0];
 #pragma unroll
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       }
       const int rl = wr * 128 + m * 16 + (lane & 15);
-      *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+      *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) =
+          MODE == 1 ? make_uint2(pack_f16(v0, v1), pack_f16(v2, v3)) : make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
     }
   }
 #undef HB_LOAD_ONE
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
         *reinterpret_cast<uint4*>(a.h + (row0 + r) * a.h_ld + col0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + r * OUT_LD + ch * 16);
     }
   } else {
-    // C51 expectation per (row, action) from the bf16 logits tile (the arithmetic of policy_kernel, policy.hip)
+    // C51 expectation per (row, action) from the fp16 logits tile (the arithmetic of policy_kernel, policy.hip)
     const int K = a.n_atoms;
     const int first_action = ct * a.group_actions;
     int ga = a.n_actions - first_action;
@@ -362,10 +372,10 @@ __global__ __launch_bounds__(NT) void actor_gemm_kernel(const GemmArgs a) {
         continue;
       }
       float mx = -INFINITY;
-      for (int k = 0; k < K; ++k) mx = fmaxf(mx, __uint_as_float(static_cast<uint32_t>(p[k]) << 16));
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, f16_lo(p[k]));
       float s = 0.f, t = 0.f;
       for (int k = 0; k < K; ++k) {
-        const float e = __expf(__uint_as_float(static_cast<uint32_t>(p[k]) << 16) - mx);
+        const float e = __expf(f16_lo(p[k]) - mx);
         s += e;
         t += e * a.support[k];
       }
@@ -535,7 +545,8 @@ __global__ __launch_bounds__(NT) void actor_gemm2_kernel(const GemmArgs a) {
             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
           }
           const int rl = m * 16 + (lane & 15);
-          *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+          *reinterpret_cast<uint2*>(lds + rl * OUT_LD + cl * 2) =
+              MODE == 1 ? make_uint2(pack_f16(v0, v1), pack_f16(v2, v3)) : make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
         }
       }
     }
@@ -566,10 +577,10 @@ __global__ __launch_bounds__(NT) void actor_gemm2_kernel(const GemmArgs a) {
         } else {
           const uint16_t* pp = reinterpret_cast<const uint16_t*>(lds + r * OUT_LD) + al * K;
           float mx = -INFINITY;
-          for (int k = 0; k < K; ++k) mx = fmaxf(mx, __uint_as_float(static_cast<uint32_t>(pp[k]) << 16));
+          for (int k = 0; k < K; ++k) mx = fmaxf(mx, f16_lo(pp[k]));
           float s = 0.f, t = 0.f;
           for (int k = 0; k < K; ++k) {
-            const float e = __expf(__uint_as_float(static_cast<uint32_t>(pp[k]) << 16) - mx);
+            const float e = __expf(f16_lo(pp[k]) - mx);
             s += e;
             t += e * a.support[k];
           }

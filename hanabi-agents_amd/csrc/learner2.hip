@@ -575,12 +575,13 @@ typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 struct ThinArgs {
   const unsigned char* x;    // bf16 [batch][M][ldx]
   const unsigned char* wt;   // bf16 [batch][N][ldw]
-  const __hip_bfloat16* bias;  // [N] or NULL
-  __hip_bfloat16* out;       // [batch][M][ldo]
+  const __hip_bfloat16* bias;  // [batch][N] or NULL
+  void* out;                 // [batch][M][ldo], bf16 or (relu & 2) fp32
   unsigned ldx, ldw, ldo;    // in elements
   unsigned x_bs, w_bs, o_bs; // batch strides in elements
-  int k, relu;
+  int k, relu;             // relu: bit 0 = ReLU, bit 1 = fp32 output
   unsigned n_tiles;        // first column tile (16 columns each) this launch covers
+  unsigned nb;             // elements between the bias rows of consecutive batch entries (= n)
 };
 __device__ __forceinline__ uint32_t tg_pack(float lo, float hi) {
   const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
@@ -594,13 +595,14 @@ __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const i
   const unsigned lr = lane & 15, kq = lane >> 4;
   const unsigned ct = blockIdx.y + a.n_tiles;   // (n_tiles: first column tile of this launch)
   const unsigned c = ct * 16u + 4u * kq;
-  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-  if (a.bias) {
-    b0 = __bfloat162float(a.bias[c]); b1 = __bfloat162float(a.bias[c + 1]); b2 = __bfloat162float(a.bias[c + 2]); b3 = __bfloat162float(a.bias[c + 3]);
-  }
   const unsigned half = 32u * a.ldx;   // byte distance of the second 16-row tile
 #pragma unroll 1
   for (int z = 0; z < batch; ++z) {
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      const __hip_bfloat16* bz = a.bias + static_cast<size_t>(z) * a.nb;
+      b0 = __bfloat162float(bz[c]); b1 = __bfloat162float(bz[c + 1]); b2 = __bfloat162float(bz[c + 2]); b3 = __bfloat162float(bz[c + 3]);
+    }
     const unsigned xo = (z * a.x_bs + (blockIdx.x * 32u + lr) * a.ldx + kq * 8u) * 2u;
     const unsigned wo = (z * a.w_bs + (ct * 16u + lr) * a.ldw + kq * 8u) * 2u;
     tg_f32x4 acc0 = tg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -613,13 +615,20 @@ __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const i
     }
     // acc_m[j] = out[row 32 bx + 16 m + (lane & 15)][col 16 by + 4 (lane >> 4) + j]
     float v[8] = {acc0[0] + b0, acc0[1] + b1, acc0[2] + b2, acc0[3] + b3, acc1[0] + b0, acc1[1] + b1, acc1[2] + b2, acc1[3] + b3};
-    if (a.relu) {
+    if (a.relu & 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
-    __hip_bfloat16* o = a.out + z * static_cast<size_t>(a.o_bs) + static_cast<size_t>(blockIdx.x * 32u + lr) * a.ldo + c;
-    *reinterpret_cast<uint2*>(o) = make_uint2(tg_pack(v[0], v[1]), tg_pack(v[2], v[3]));
-    *reinterpret_cast<uint2*>(o + 16u * static_cast<size_t>(a.ldo)) = make_uint2(tg_pack(v[4], v[5]), tg_pack(v[6], v[7]));
+    const size_t oo = z * static_cast<size_t>(a.o_bs) + static_cast<size_t>(blockIdx.x * 32u + lr) * a.ldo + c;
+    if (a.relu & 2) {   // fp32 output: the accumulators as they are (the loss kernel's logits)
+      float* o = static_cast<float*>(a.out) + oo;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 16u * static_cast<size_t>(a.ldo)) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      __hip_bfloat16* o = static_cast<__hip_bfloat16*>(a.out) + oo;
+      *reinterpret_cast<uint2*>(o) = make_uint2(tg_pack(v[0], v[1]), tg_pack(v[2], v[3]));
+      *reinterpret_cast<uint2*>(o + 16u * static_cast<size_t>(a.ldo)) = make_uint2(tg_pack(v[4], v[5]), tg_pack(v[6], v[7]));
+    }
   }
 }
 
@@ -664,14 +673,16 @@ int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, vo
   if (m <= 0 || n <= 0 || batch <= 0) return HB_OK;
   if (m % 32 || n % 16 || k % 32 || k < 32) return fail(HB_ERR_INVALID, "need m % 32 == 0, n % 16 == 0, k % 32 == 0");
   if (ldx < k || ldw < k || ldo < n || ldx % 8 || ldw % 8 || ldo % 4) return fail(HB_ERR_INVALID, "bad leading dimensions");
-  if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) || (reinterpret_cast<uintptr_t>(wt_dev) & 15u) || (reinterpret_cast<uintptr_t>(out_dev) & 7u))
-    return fail(HB_ERR_ALIGN, "x / wt must be 16-byte aligned, out 8-byte aligned");
+  if (relu < 0 || relu > 3) return fail(HB_ERR_INVALID, "relu: bit 0 = ReLU, bit 1 = fp32 output");
+  if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) || (reinterpret_cast<uintptr_t>(wt_dev) & 15u) ||
+      (reinterpret_cast<uintptr_t>(out_dev) & ((relu & 2) ? 15u : 7u)))
+    return fail(HB_ERR_ALIGN, "x / wt must be 16-byte aligned, out 8-byte (fp32 output: 16-byte) aligned");
   const int64_t xe = (batch - 1) * x_batch_stride + m * static_cast<int64_t>(ldx), we = (batch - 1) * w_batch_stride + n * static_cast<int64_t>(ldw);
   if (xe >= (1LL << 30) || we >= (1LL << 30)) return fail(HB_ERR_INVALID, "operands beyond the kernel's 32-bit offsets");
   ThinArgs a{static_cast<const unsigned char*>(x_dev), static_cast<const unsigned char*>(wt_dev),
-             static_cast<const __hip_bfloat16*>(bias_dev), static_cast<__hip_bfloat16*>(out_dev), static_cast<unsigned>(ldx),
+             static_cast<const __hip_bfloat16*>(bias_dev), out_dev, static_cast<unsigned>(ldx),
              static_cast<unsigned>(ldw), static_cast<unsigned>(ldo), static_cast<unsigned>(x_batch_stride),
-             static_cast<unsigned>(w_batch_stride), static_cast<unsigned>(out_batch_stride), k, relu, 0u};
+             static_cast<unsigned>(w_batch_stride), static_cast<unsigned>(out_batch_stride), k, relu, 0u, static_cast<unsigned>(n)};
   // at most 1 024 workgroups (= wavefronts) per launch: one per SIMD of the chip, so that an actor-GEMM workgroup arriving
   // while this kernel runs still finds its registers; wider outputs take several launches
   const unsigned tiles = static_cast<unsigned>(n / 16), gx = static_cast<unsigned>(m / 32), cap = gx >= 1024u ? 1u : 1024u / gx;

@@ -70,7 +70,7 @@ class FusedLearner:
             self.w1catT = torch.zeros(2 * H, self.Kp, dtype=self.cd, device=dev)
             self.w2stT = torch.zeros(2, self.Np, H, dtype=self.cd, device=dev)
             self._hcat = torch.zeros(2 * B, 2 * H, dtype=self.cd, device=dev)
-            self._logits = torch.zeros(2, 2 * B, self.Np, dtype=self.cd, device=dev)
+            self._logits = torch.zeros(2, 2 * B, self.Np, **f32)   # fp32: the accumulators + bias as they are (round 3; bf16 before)
             self._bias_sink = torch.zeros(max(2 * H, self.Np), **f32)   # (the transposer also converts a bias: unused here)
             self._t_jobs = [None, None]
         # flat gradient buffer [dW1 | db1 | dW2 | db2] (fp32), one all-reduce bucket
@@ -264,31 +264,36 @@ class FusedLearner:
             self._transpose(0)
             K.check(L.hb_thin_gemm(K.dptr(self.x), K.dptr(self.w1catT), K.dptr(self.b1cat), K.dptr(hcat), 2 * B, 2 * H, self.Kp,
                                    self.Kp, self.Kp, 2 * H, 1, 0, 0, 0, 1, s))                       # bias + ReLU, [2B, 2H]
-            K.check(L.hb_thin_gemm(K.dptr(hcat), K.dptr(self.w2stT), None, K.dptr(logits), 2 * B, self.Np, H, 2 * H, H, self.Np,
-                                   2, H, self.Np * H, 2 * B * self.Np, 0, s))                        # {online, target}: [2, 2B, Np]
+            K.check(L.hb_thin_gemm(K.dptr(hcat), K.dptr(self.w2stT), K.dptr(self.b2st), K.dptr(logits), 2 * B, self.Np, H, 2 * H, H,
+                                   self.Np, 2, H, self.Np * H, 2 * B * self.Np, 2, s))               # {online, target}: [2, 2B, Np] fp32, biases added
         else:
             hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
             logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy
         logits_on, logits_t = logits[0], logits[1, B:]                                   # online on all 2B rows, target on obs_t
         hb, xb = hcat[:B, :H], self.x[:B]
+        # thin forward: fp32 logits that already contain the output biases; library GEMMs: logits in the GEMM dtype, biases added by the loss kernel
+        ldt = 0 if self.thin else _DT[self.cd]
+        bon, btg = (None, None) if self.thin else (self.b2st[0], self.b2st[1])
         if self.sparse_backward:
             # dLoss/dlogits is non-zero only in the K atoms of the action each sample took: the loss kernel emits that compact
             # [B, 64] fp32 form and ONE launch turns it into dH (ReLU-masked), db1, dW2 and db2 (csrc/learner2.hip)
-            K.check(L.hb_c51_loss_sparse(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
+            K.check(L.hb_c51_loss_sparse(K.dptr(logits_on), K.dptr(logits_t), ldt, K.dptr(self.act), K.dptr(self.rew),
                                          K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
                                          1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
                                          K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dl), K.dptr(self.step),
-                                         K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
+                                         K.dptr(bon), K.dptr(btg), s))
             K.check(L.hb_c51_backward(K.dptr(self.dl), K.dptr(self.act), K.dptr(hb), hb.stride(0), K.dptr(w2), w2.stride(0),
                                       _DT[self.cd], B, H, self.A, self.Kk, K.dptr(self.dh), K.dptr(self.g_b1),
                                       K.dptr(self._gw2_out), self.Np, K.dptr(self._gb2_pad), s))
             dh = self.dh
         else:   # the dense chain of the first fused learner: kept as a cross-check (tests) of the sparse kernels
-            K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), _DT[self.cd], K.dptr(self.act), K.dptr(self.rew),
+            if self.thin:   # (this cross-check chain keeps its GEMM-dtype gradient: give it logits of that dtype; biases are already in)
+                logits_on, logits_t, ldt = logits_on.to(self.cd), logits_t.to(self.cd), _DT[self.cd]
+            K.check(L.hb_c51_loss_grad(K.dptr(logits_on), K.dptr(logits_t), ldt, K.dptr(self.act), K.dptr(self.rew),
                                        K.dptr(self.term), K.dptr(prios), K.dptr(a._beta), K.dptr(self.disc),
                                        1 if a.params.mask_terminal else 0, K.dptr(self.support), B, self.A, self.Kk, self.Np,
                                        K.dptr(self.td), K.dptr(self.w_is), K.dptr(self.dlogits), K.dptr(self.step),
-                                       K.dptr(self.b2st[0]), K.dptr(self.b2st[1]), s))
+                                       K.dptr(bon), K.dptr(btg), s))
             dl = self.dlogits
             torch.mm(hb.t(), dl, out=self._gw2_out)                       # [H, Np]; the padding columns are never read
             K.check(L.hb_colsum(K.dptr(dl), _DT[self.cd], B, self.Np, K.dptr(self._gb2_pad), s))

@@ -98,6 +98,9 @@ class ActorMFMA:
                            torch.zeros(b2.value // 2, **bf), torch.zeros(nb.value, dtype=torch.float32, device=device))
                           for _ in range(self.n_sets)]
         self._fset_ptrs = [tuple(t.data_ptr() for t in st) for st in self.fsets]
+        # one workgroup owns 128 rows from start to end, so below ~one workgroup per two CUs the two-kernel form (more, smaller
+        # workgroups) is quicker: measured 58 vs 45 us at 4 096 rows, 56 vs 48 at 7 000, equal at 16 384, 49 vs 69 at 32 768
+        self.fused_min_rows = int(os.environ.get("HB_ACTOR_FUSED_MIN_ROWS", "16385"))
 
     def state_tensors(self):
         """Every packed weight copy of every set (checkpoints: with actor_lag the acting set is state of its own)."""
@@ -150,7 +153,7 @@ class ActorMFMA:
                                 self.h.data_ptr(), self.q.data_ptr(), support.data_ptr())
         _, n, hidden, qfn, hp, qp, sp = c
         st = K.current_stream()
-        if self.fused and obs.dtype == torch.int32:
+        if self.fused and obs.dtype == torch.int32 and n >= self.fused_min_rows:
             f = self._fset_ptrs[s]
             K.check(K.lib().hb_actor_fused_q(c[0], n, self.obs_len, f[0], f[1], f[2], f[3], sp, self.hidden, self.n_actions,
                                              self.n_atoms, qp, st))
@@ -171,7 +174,7 @@ class ActorMFMA:
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
             self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
         actions = torch.empty(n, dtype=torch.int32, device=obs.device)
-        if self.fused and packed:
+        if self.fused and packed and n >= self.fused_min_rows:
             f = self._fset_ptrs[s]
             st = K.current_stream()
             K.check(K.lib().hb_actor_fused_q(obs.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3], support.data_ptr(), self.hidden,

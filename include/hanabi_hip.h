@@ -419,12 +419,14 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
                        int32_t n_atoms, int32_t row_stride, float* td_dev, float* w_dev, float* dl_dev, float* update_counter_dev,
                        const void* bias_online_dev, const void* bias_target_dev, void* stream);
 
-/* hb_thin_gemm: out[b][m, n] = act(sum_k x[b][m, k] * wt[b][n, k] + bias[n]) in bf16 with fp32 accumulation, both operands
+/* hb_thin_gemm: out[b][m, n] = act(sum_k x[b][m, k] * wt[b][n, k] + bias[b][n]) in bf16 with fp32 accumulation, both operands
  * k-contiguous (wt is the TRANSPOSED weight matrix, as hb_actor_pack_weights writes it), as a kernel small enough (one
  * wavefront per workgroup, 36 VGPRs, no LDS) to run on the CUs WHILE hb_actor_hidden / hb_actor_q hold them: the dense layers
  * of DQNLearning.update_q's forward pass (rlax_rainbow.py:172-185 over noisy_mlp.py:176-185) then proceed during the other
  * seat's policy forward instead of queueing behind it. m % 32 == 0, n % 16 == 0, k % 32 == 0; batch >= 1 with element strides;
- * bias (bf16, may be NULL) and ReLU are applied before the bf16 rounding, like a library GEMM epilogue.                      */
+ * bias (bf16 [batch][n], may be NULL) and ReLU are applied before the bf16 rounding, like a library GEMM epilogue.
+ * relu: bit 0 = ReLU; bit 1 = write fp32 instead of bf16 (ldo / out_batch_stride then count floats, out_dev 16-byte aligned):
+ * the learner's logits are the accumulators + bias as they are (round 3), so the loss sees no bf16 rounding of the logits.    */
 int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
                  int32_t ldx, int32_t ldw, int32_t ldo, int32_t batch, int64_t x_batch_stride, int64_t w_batch_stride,
                  int64_t out_batch_stride, int32_t relu, void* stream);

@@ -23,6 +23,7 @@ support = torch.linspace(-25, 25, NA, device=dev)
 
 os.environ["HB_ACTOR_FUSED"] = "1"
 act = ops.ActorMFMA(L, H, A, NA, Kp, dev)
+act.fused_min_rows = 0
 assert act.fused, "shape not covered"
 act.pack(w1, b1, w2, b2)
 q_f = act.q_values(bits, support).clone()

@@ -27,6 +27,7 @@ w2 = torch.zeros(H, Np, device=dev, dtype=torch.bfloat16); w2[:, :A * NA] = (tor
 b2 = torch.zeros(Np, device=dev, dtype=torch.bfloat16); b2[:A * NA] = (torch.randn(A * NA, device=dev) * 0.5).bfloat16()
 support = torch.linspace(-25, 25, NA, device=dev)
 act = ops.ActorMFMA(L, H, A, NA, Kp, dev)
+act.fused_min_rows = 0
 act.pack(w1, b1, w2, b2)
 lib = K.lib()
 lib.hb_actor_fused_q_stamped.restype = C.c_int
@@ -38,7 +39,7 @@ f = act._fset_ptrs[0]
 for _ in range(200):   # (clock settles under load)
     act.q_values(bits, support)
 names = ["prologue (table, bits)", "barrier", "layer 1 loop", "H write, early rows", "barrier + late rows", "barrier", "pass 0 loop", "pass 0 epilogue",
-         "arrive (+ merge)", "pass 1 loop", "pass 1 epilogue", "arrive (+ merge)"]
+         "barrier + merge", "pass 1 loop", "pass 1 epilogue", "barrier + merge"]
 rows = []
 for _ in range(10):
     K.check(lib.hb_actor_fused_q_stamped(bits.data_ptr(), N, L, f[0], f[1], f[2], f[3], support.data_ptr(), H, A, NA, q.data_ptr(),

@@ -2,11 +2,12 @@
 hanabi_agents/rlax_dqn/rlax_rainbow.py:250-251) against the fp32 PyTorch-autograd path, with the STATED tolerances of
 hanabi_agents/rlax_dqn/tolerance.py (include/hanabi_hip.h).
 
-Learner: FusedLearner (hb_replay_gather -> hipBLASLt GEMMs -> hb_c51_loss_grad -> hand backward -> hb_noisy_adam_multi) at
-compute_dtype bf16 / fp16 vs DQNLearning.loss + torch.optim.Adam in fp32 (loss of rlax_rainbow.py:172-200) on the same
-batch, weights, sampling probabilities: per-sample td, IS weights, loss, the four merged gradients after one step, the
-weights after five. Actor: hb_actor_hidden + hb_actor_q (hand-written MFMA, bf16) and the fp16 library-GEMM fallback vs
-DQNPolicy.q_values in fp32 at the 2-player and 5-player shapes, arg-max agreement wherever the fp32 top-2 gap is clear.
+Learner: FusedLearner (hb_per_sample_gather / hb_replay_gather -> hb_thin_gemm forward with fp32 logits (bf16; library GEMMs for
+fp16) -> hb_c51_loss_sparse -> hb_c51_backward -> dW1 GEMM -> hb_noisy_adam_multi) at compute_dtype bf16 / fp16 vs
+DQNLearning.loss + torch.optim.Adam in fp32 (loss of rlax_rainbow.py:172-200) on the same batch, weights, sampling
+probabilities: per-sample td, IS weights, loss, the four merged gradients after one step, the weights after five. Actor (bf16):
+hb_actor_fused_q on bit rows (the benched form) and hb_actor_hidden + hb_actor_q on int8 rows; fp16: the library-GEMM fallback;
+all vs DQNPolicy.q_values in fp32 at the 2-player and 5-player shapes, arg-max agreement wherever the fp32 top-2 gap is clear.
 Measured errors are written to gpurun_out/dtype_parity.json next to the bounds."""
 import json
 import os
@@ -155,13 +156,14 @@ def test_fused_learner_reduced_precision_vs_fp32_autograd(dtype, players):
 
 
 @pytest.mark.parametrize("players", [2, 5])
-@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, players):
-    """bf16: hb_actor_hidden + hb_actor_q (csrc/actor.hip). fp16: hb_obs_cast + library GEMMs + hb_policy_act (the
-    fallback `_act_fused` takes for dtypes the MFMA kernels do not cover). Both against DQNPolicy.q_values in fp32."""
+@pytest.mark.parametrize("dtype,form", [("bfloat16", "bits"), ("bfloat16", "int8"), ("float16", "int8")])
+def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, form, players):
+    """bf16, bit rows: hb_actor_fused_q (csrc/actor_fused.hip, the benched form). bf16, int8 rows: hb_actor_hidden + hb_actor_q
+    (csrc/actor.hip). fp16: hb_obs_cast + library GEMMs + hb_policy_act (the fallback `_act_fused` takes for dtypes the MFMA
+    kernels do not cover). All against DQNPolicy.q_values in fp32."""
     import torch
 
-    from hanabi_agents.rlax_dqn import DQNPolicy
+    from hanabi_agents.rlax_dqn import DQNPolicy, bitpack
     from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
     from hanabi_hip import ops
 
@@ -179,7 +181,10 @@ def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, players):
     fl.refresh_effective()
     q32 = DQNPolicy.q_values(ref.online, ref.atoms, obs.float(), legal)
     fused._draws = 3
-    act = fused._act_fused(obs, legal, 0.0)
+    if form == "bits":
+        assert fl.actor is not None and fl.actor.fused, "the fused actor kernel must cover the benched shape"
+        fl.actor.fused_min_rows = 0
+    act = fused._act_fused(bitpack.pack(obs) if form == "bits" else obs, legal, 0.0)
     if dtype == "bfloat16":
         assert fl.actor is not None, "the MFMA actor must cover the benched shape"
         q_lp = fl.actor.q.clone()
@@ -202,7 +207,7 @@ def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, players):
     measured = {"q_max_abs_err": float(err.max()), "q_mean_abs_err": float(err.mean()), "q_abs_mean": float(q32f[lm].abs().mean()),
                 "rows_with_clear_gap": float(clear.float().mean()), "argmax_agreement_all_rows": float(agree.float().mean()),
                 "median_top2_gap": float(gap.median())}
-    _record(f"actor_{dtype}_{players}p", {"measured": measured, "tolerance": {k: tol[k] for k in ("q_abs", "argmax_gap")}})
+    _record(f"actor_{dtype}_{form}_{players}p", {"measured": measured, "tolerance": {k: tol[k] for k in ("q_abs", "argmax_gap")}})
     assert measured["q_max_abs_err"] <= tol["q_abs"], measured
     assert measured["rows_with_clear_gap"] > 0.3, measured
     assert bool(agree[clear].all()), measured

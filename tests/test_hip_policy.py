@@ -729,5 +729,15 @@ def test_thin_gemm_equals_fp32_reference(m, n, k, batch, relu):
         err = (out[b].float() - ref).abs()
         assert float(err.max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-3, (b, float(err.max()))
         assert torch.equal(out[b], ref.to(torch.bfloat16)) or float((out[b] != ref.to(torch.bfloat16)).float().mean()) < 0.02
+    # fp32 output (relu bit 1) with one bias row per batch entry: the accumulators + bias as they are (the learner's logits)
+    bias2 = (torch.randn(batch, n, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    out32 = torch.full((batch, m, n), 7.0, dtype=torch.float32, device="cuda")
+    K.check(K.lib().hb_thin_gemm(K.dptr(x), K.dptr(wt), K.dptr(bias2), K.dptr(out32), m, n, k, ldx, k, n, batch, k, n * k, m * n,
+                                 (1 if relu else 0) | 2, K.current_stream()))
+    for b in range(batch):
+        ref = x[:, b * k:(b + 1) * k].float() @ wt[b].float().t() + bias2[b].float()
+        if relu:
+            ref = torch.relu(ref)
+        assert float((out32[b] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5
     with pytest.raises(K.HbError):
         K.check(K.lib().hb_thin_gemm(K.dptr(x), K.dptr(wt), None, K.dptr(out), m + 1, n, k, ldx, k, n, 1, 0, 0, 0, 0, K.current_stream()))
