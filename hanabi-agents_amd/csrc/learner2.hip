@@ -421,7 +421,7 @@ __global__ __launch_bounds__(BWD_T) void c51_backward_kernel(const BwdArgs a) {
   const int s_begin = sq * per, s_end = s_begin + per < n ? s_begin + per : n;
   // One memory round trip for everything the accumulation needs: this lane's hidden activations of its (at most 32) samples
   // into registers, and the dl rows of ALL the action's samples into LDS (every thread a few independent 16-byte loads)
-  float* dls = reinterpret_cast<float*>(smem) + a.B;    // [n][64] behind the list
+  float* dls = reinterpret_cast<float*>(smem) + ((a.B + 3) & ~3);    // [n][64] behind the list, on a 16-byte boundary for ANY batch size (float4 accesses)
   float hreg[32];
 #pragma unroll
   for (int u = 0; u < 32; ++u) {
@@ -491,7 +491,7 @@ int launch_backward(const BwdArgs& a0, hipStream_t s) {
   BwdArgs a = a0;
   const size_t row = static_cast<size_t>(a.A) * (sizeof(T) == 2 ? 72 : 68) * sizeof(T);
   const int n_jt = (a.H + 63) / 64;
-  const size_t list_bytes = static_cast<size_t>(a.B) * 4;
+  const size_t list_bytes = static_cast<size_t>((a.B + 3) & ~3) * 4;   // (rounded up: the staged rows behind it are read as float4)
   // hidden units per dH tile: 8 (64 workgroups for 512 units; bf16, 20 actions: 23 KB of LDS), fewer if LDS is short
   int jt = 8;
   while (jt > 1 && jt * row + 16 * jt * 4 > 64 * 1024) jt >>= 1;

@@ -49,6 +49,7 @@ struct hb_tree {
   long long scratch_n;
   bool single_wg;     // measurements only (env HB_TREE_UPDATE_PATH=single at creation): force update_small
   bool lazy_top;      // hb_tree_set_lazy_top: writers leave the levels above the 1024-leaf subtrees stale, readers re-sum them
+  bool top_stale;     // lazy mode was switched off: the stored top levels are made valid by the next reader or writer, on ITS stream
 };
 
 namespace {
@@ -517,7 +518,8 @@ void launch_top(hb_tree* t, hipStream_t s) {
 }
 // lazy mode: the levels above the subtree roots are only as fresh as the last reader made them
 void freshen_top(hb_tree* t, hipStream_t s) {
-  if (t->lazy_top) launch_top(t, s);
+  if (t->lazy_top || t->top_stale) launch_top(t, s);
+  if (!t->lazy_top) t->top_stale = false;
 }
 
 int rebuild(hb_tree* t, int first_chunk, int nchunks_touched, hipStream_t s) {
@@ -553,6 +555,7 @@ int hb_tree_create(int64_t capacity, hb_tree** out) {
   t->scratch = nullptr;
   t->scratch_n = 0;
   t->lazy_top = false;
+  t->top_stale = false;
   {
     const char* path = getenv("HB_TREE_UPDATE_PATH");
     t->single_wg = path && path[0] == 's';
@@ -742,7 +745,10 @@ int hb_tree_total(hb_tree* t, float* total_dev, void* stream) {
 
 int hb_tree_set_lazy_top(hb_tree* t, int32_t on) {
   if (!t) return fail(HB_ERR_INVALID, "null tree");
-  if (t->lazy_top && !on) launch_top(t, nullptr);   // leaving lazy mode: make the stored top levels valid again
+  // Leaving lazy mode: the stored top levels are stale. They are NOT re-summed here — this call has no stream, and the tree's
+  // writers run on the caller's (non-blocking) streams, so a launch on the NULL stream would not be ordered behind them — but
+  // by the next reader or writer, on the stream that call is given (every writer of the non-lazy mode ends with the re-sum).
+  if (t->lazy_top && !on) t->top_stale = true;
   t->lazy_top = on != 0;
   return HB_OK;
 }

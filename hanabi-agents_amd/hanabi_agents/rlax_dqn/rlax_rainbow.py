@@ -461,7 +461,7 @@ class DQNAgent:
                 start = buf.oldest_entry
                 if self.params.use_priority:
                     if self.split_update:
-                        self._pending_fills.append((start, n))
+                        self._queue_fill(start, n)
                     else:
                         buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
                 c[2](*c[3], start, c[4]())
@@ -478,7 +478,7 @@ class DQNAgent:
                     # the sum tree is written ONLY on the stream the updates run on. The leaves of these rows are set by the
                     # next update_begin(), i.e. after the priority write-back of the update in flight and before the next
                     # sampling: the same order of tree writes as in the plain sequential form.
-                    self._pending_fills.append((start, n))
+                    self._queue_fill(start, n)
                 else:
                     buf.sum_tree.fill_range_dev(start, n, buf._max_priority)
             ins = (self.last_obs, self._obs_store(obs).contiguous(), legal.to(torch.int8).contiguous(),
@@ -534,6 +534,21 @@ class DQNAgent:
             self.split_update = on
             self._graph1 = self._graph2 = None   # the captured update has the other shape: capture again at the next update
         return on
+
+    def _queue_fill(self, start, n):
+        """split update: remember that rows [start, start + n) of the ring were inserted. Contiguous inserts merge into one range
+        (a seat that inserts without training — train=False, or a seat outside train_seats — would otherwise grow the list by one
+        entry, and the next drain by one launch, per step); once a whole ring's worth is queued the list is the whole ring.
+        Until the list is drained (update_begin / sync / checkpoint_state) the sum tree does not know these rows: code that reads
+        the tree directly between steps must call sync() first."""
+        cap = self.experience.capacity
+        pf = self._pending_fills
+        if pf and pf[-1][0] + pf[-1][1] == start and pf[-1][1] + n <= cap:
+            pf[-1] = (pf[-1][0], pf[-1][1] + n)
+        else:
+            pf.append((start, n))
+        if len(pf) > 1 and sum(x[1] for x in pf) >= cap:
+            pf[:] = [(0, cap)]
 
     def apply_pending_fills(self):
         """split update: set the sum-tree leaves of the rows inserted since the last update (on the CURRENT stream, which must be
@@ -797,6 +812,9 @@ class DQNAgent:
     def _snapshot_learner_state(self):
         snap = dict(tensors=[t.clone() for t in self._learner_state_tensors()], last_loss=self._last_loss,
                     rng=torch.cuda.get_rng_state(self.device), gen=self._gen.get_state())
+        xg = getattr(self.experience, "_gen", None)   # uniform replay draws its batch indices from the buffer's own generator
+        if xg is not None:
+            snap["xgen"] = xg.get_state()
         if self.params.use_priority:
             snap["tree"] = self.experience.sum_tree.nodes().clone()
         if self._fl is None:
@@ -819,6 +837,8 @@ class DQNAgent:
                             v.zero_() if old is None else v.copy_(old[k])
         torch.cuda.set_rng_state(snap["rng"], self.device)
         self._gen.set_state(snap["gen"])
+        if "xgen" in snap:
+            self.experience._gen.set_state(snap["xgen"])
         self._last_loss = snap["last_loss"]
         self._eff_cache = None
         if self._fv is not None:
@@ -989,7 +1009,6 @@ class DQNAgent:
                 fl.pack_actor()
                 sd["fused"]["actor_sets"] = [t.cpu() for t in fl.actor.state_tensors()]
                 sd["fused"]["n_packed"] = fl.n_packed
-                sd["pending_fills"] = [list(x) for x in self._pending_fills]
         else:
             sd["optimizer"] = self.optimizer.state_dict()
         return sd
@@ -1032,7 +1051,7 @@ class DQNAgent:
                     for dst, src in zip(fl.actor.state_tensors(), f["actor_sets"]):
                         dst.copy_(src)
                     fl.n_packed, fl.packed_ev, fl.actor_stale = int(f["n_packed"]), [None, None], False
-                    self._pending_fills = [tuple(x) for x in sd.get("pending_fills", [])]
+                    self._pending_fills = []   # (checkpoint_state drains the list before it writes the tree)
             else:
                 self.optimizer.load_state_dict(sd["optimizer"])
                 self._trg_cache = None

@@ -255,7 +255,9 @@ typedef struct hb_tree hb_tree;
 int hb_tree_create(int64_t capacity, hb_tree** out); /* capacity rounds up to a power of two (sum_tree.h:28) */
 int hb_tree_destroy(hb_tree* t);
 int64_t hb_tree_capacity(const hb_tree* t);          /* get_capacity() */
-/* device pointer to the 2*cap floats of the heap (zero-copy consumers) */
+/* device pointer to the 2*cap floats of the heap (zero-copy consumers). While lazy top levels are on (hb_tree_set_lazy_top), and
+ * after they are switched off until the next hb_tree_* call that is given a stream, nodes[1 .. cap / 1024) — the levels above
+ * the 1024-leaf subtrees, the root included — may be stale: read the total with hb_tree_total, never as nodes[1].           */
 float* hb_tree_nodes(hb_tree* t);
 /* copy of the whole heap into nodes_dev[2*cap] (differential tests) */
 int hb_tree_export_nodes(hb_tree* t, float* nodes_dev, void* stream);
@@ -267,7 +269,8 @@ int hb_tree_import_nodes(hb_tree* t, const float* nodes_dev, void* stream);
  * subtrees they touch and then re-sum the levels above them in a second, one-workgroup launch. on != 0 drops that launch:
  * the levels above the subtree roots go stale and every READER makes them fresh first — hb_per_sample_gather inside its own
  * workgroups (in LDS, the same pairwise sums: identical bits), the other readers (hb_tree_sample, hb_per_sample[_philox],
- * hb_tree_total, hb_tree_export_nodes) by running the re-sum launch themselves. Results never depend on the mode.          */
+ * hb_tree_total, hb_tree_export_nodes) by running the re-sum launch themselves. Results never depend on the mode.
+ * on == 0 launches nothing (it has no stream): the levels are re-summed by the next reader or writer, on that call's stream. */
 int hb_tree_set_lazy_top(hb_tree* t, int32_t on);
 
 /* update_values(indices, values) (sum_tree.h:38-44). Duplicate indices inside one call:

@@ -35,6 +35,9 @@ def make_config(game="Hanabi-Full", players=2, flags=0):
 
 
 def build(force=False):
+    # HB_ORACLE_LIB: another build of the same sources, e.g. the sanitizer build `make -C oracle asan` (oracle/Makefile)
+    if os.environ.get("HB_ORACLE_LIB"):
+        return os.environ["HB_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "hanabi_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -199,3 +199,25 @@ def test_scalar_double_dqn_head():
     agent.add_experience((None, (o, legal)), agent.explore((None, (o, legal))), np.ones(4), np.ones(4))
     agent.update()
     assert torch.isfinite(agent.last_loss)
+
+
+def test_pending_tree_fills_are_coalesced_and_bounded():
+    """split update: inserts only queue (start, rows) for the sum tree; a seat that inserts without training must not grow that
+    list by one entry per step: contiguous ranges merge, a ring wrap starts a new range, and a whole ring's worth
+    collapses to the whole ring."""
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    agent = DQNAgent(ObservationSpec((4, 171)), ActionSpec(11), RlaxRainbowParams(experience_buffer_size=64, train_batch_size=4, use_priority=False),
+                     device="cpu")
+    for start in (0, 4, 8, 12):
+        agent._queue_fill(start, 4)
+    assert agent._pending_fills == [(0, 16)]
+    agent._queue_fill(60, 4)            # not contiguous with the previous range
+    agent._queue_fill(0, 4)             # the ring wrapped: a new range
+    assert agent._pending_fills == [(0, 16), (60, 4), (0, 4)]
+    for start in range(4, 64, 4):
+        agent._queue_fill(start, 4)
+    assert agent._pending_fills == [(0, 64)]
+    for _ in range(1000):               # a frozen seat in a long run
+        agent._queue_fill(0, 64)
+    assert len(agent._pending_fills) == 1
