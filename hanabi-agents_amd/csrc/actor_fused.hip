@@ -30,6 +30,7 @@
 
 #include "../../include/hanabi_hip.h"
 #include "common.hpp"
+#include "env_kernel.hpp"  // philox4x32_10
 
 using hb::fail;
 
@@ -61,6 +62,13 @@ struct FusedArgs {
   const float* support;    // [51]
   float* q;                // [m][n_actions]
   int n_actions, n_pass;
+  // hb_actor_fused_act: the epsilon-greedy selection of hb_policy_select (csrc/actor.hip, select_rows: same rule, same Philox
+  // draws, identical actions) as the workgroup's last act, on the q rows it has just written
+  const int8_t* legal;     // [m][n_actions], or NULL: q values only
+  int32_t* actions;        // [m]
+  float epsilon;
+  unsigned long long seed, draw;
+  long long first_gid;
   unsigned long long* stamps;   // diagnostic builds only (-DHB_STAMPS): 16 u64 per wavefront
 };
 
@@ -447,6 +455,43 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     }
     if (p < 2) HB_FSTAMP(9 + 3 * p);
   }
+  if (a.legal) {
+    // ---- action selection for the workgroup's 128 rows, one lane per row. The q values were stored by all eight wavefronts:
+    // every wavefront drains its stores (they are complete once L2 has them), the barrier orders that before the reads, and the
+    // reads are device-scope loads (served by L2, never by this CU's L1).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < FM && row0 + tid < a.m) {
+      const long long g = row0 + tid;
+      const unsigned long long gid = static_cast<unsigned long long>(a.first_gid + g);
+      uint32_t rnd[4];
+      hb::philox4x32_10(static_cast<uint32_t>(a.draw), static_cast<uint32_t>(a.draw >> 32), static_cast<uint32_t>(gid),
+                        static_cast<uint32_t>(gid >> 32), static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), rnd);
+      const float* qr = a.q + g * A;
+      const int8_t* lr = a.legal + g * A;
+      float best = -INFINITY;
+      unsigned long long legal_mask = 0, ties = 0;
+      for (int i = 0; i < A; ++i) {
+        const float v = __hip_atomic_load(qr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lr[i] != 0) {
+          legal_mask |= 1ull << i;
+          if (v > best) { best = v; ties = 1ull << i; }
+          else if (v == best) ties |= 1ull << i;
+        }
+      }
+      const float u = static_cast<float>(rnd[0] >> 8) * (1.0f / 16777216.0f);
+      unsigned long long pool = (u < a.epsilon) ? legal_mask : ties;
+      if (pool == 0) pool = legal_mask;
+      int pick = 0;
+      const int c = __popcll(pool);
+      if (c > 0) {
+        int k = static_cast<int>(__umulhi(rnd[1], static_cast<uint32_t>(c)));
+        while (k-- > 0) pool &= pool - 1;
+        pick = __ffsll(static_cast<long long>(pool)) - 1;
+      }
+      a.actions[g] = pick;
+    }
+  }
   HB_FSTAMP_REAL(15);
 }
 
@@ -542,15 +587,33 @@ int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, c
   return HB_OK;
 }
 
+struct FusedSelect {
+  const int8_t* legal;
+  int32_t* actions;
+  float epsilon;
+  uint64_t seed, draw;
+  int64_t first_gid;
+};
 static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                         const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
-                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream);
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, void* stream);
 
 int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                      const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions, int32_t n_atoms,
                      float* q_dev, void* stream) {
   return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
-                      nullptr, stream);
+                      nullptr, nullptr, stream);
+}
+
+int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev,
+                       const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
+                       int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
+                       int64_t first_game_id, int32_t* actions_dev, void* stream) {
+  if (!legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64 for the fused selection");
+  const FusedSelect sel{legal_dev, actions_dev, epsilon, seed, draw, first_game_id};
+  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
+                      nullptr, &sel, stream);
 }
 
 #ifdef HB_STAMPS
@@ -559,13 +622,13 @@ int hb_actor_fused_q_stamped(const uint32_t* obs_bits_dev, int64_t n_rows, int32
                              const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
                              int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream) {
   return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
-                      stamps_dev, stream);
+                      stamps_dev, nullptr, stream);
 }
 #endif
 
 static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                         const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
-                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream) {
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, void* stream) {
   if (!obs_bits_dev || !w1f_dev || !b1f_dev || !w2f_dev || !b2f_dev || !support_dev || !q_dev) return fail(HB_ERR_INVALID, "null argument");
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
   if (n_rows <= 0) return HB_OK;
@@ -576,6 +639,10 @@ static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t ob
   a.w1f = static_cast<const uint4*>(w1f_dev); a.b1 = b1f_dev; a.w2f = static_cast<const uint4*>(w2f_dev); a.b2 = b2f_dev;
   a.support = support_dev; a.q = q_dev; a.n_actions = n_actions; a.n_pass = passes_for(n_actions);
   a.stamps = stamps_dev;
+  if (sel) {
+    a.legal = sel->legal; a.actions = sel->actions; a.epsilon = sel->epsilon; a.seed = sel->seed; a.draw = sel->draw;
+    a.first_gid = sel->first_gid;
+  }
   const dim3 grid(static_cast<unsigned>((n_rows + FM - 1) / FM));
   hipLaunchKernelGGL(actor_fused_kernel, grid, dim3(FNT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());

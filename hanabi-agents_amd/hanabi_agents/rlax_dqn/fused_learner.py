@@ -130,6 +130,7 @@ class FusedLearner:
         if self.lag not in (0, 1):
             raise ValueError("actor_lag must be 0 or 1")
         self.n_packed = 0
+        self._packed_in_part2 = False
         self.packed_ev = [None, None]
         if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd) and getattr(agent, "use_mfma_actor", True):
             self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev, n_sets=2 if self.lag else 1)
@@ -177,14 +178,15 @@ class FusedLearner:
         if self.actor is not None and self.actor_stale:
             (w1, b1), (w2, b2) = self.eff
             for s in range(self.actor.n_sets):
-                self.actor.pack(w1, b1, w2, b2, s)
+                self.actor.pack(w1, b1, w2, b2, s, lazy_two_kernel=not self.lag)
             self.actor_stale = False
             self.packed_ev = [None, None]
 
     def weights_updated(self):
         """Called after every optimizer step, on the stream the step ran on."""
         if not self.lag:
-            self.actor_stale = True   # repacked lazily before the next policy call
+            # part2() has already re-packed the actor's copies behind Adam, on the stream (and inside the graph) the update ran on
+            self.actor_stale = self.actor is not None and not self._packed_in_part2
             return
         self.pack_actor()
         s = self.n_packed % 2
@@ -338,6 +340,15 @@ class FusedLearner:
         # self.step was advanced by this update's loss kernel (part1): it already is this step's number
         K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
                                             float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
+        # Synchronous agent: the actor's weight copies follow Adam right here — on the learner's stream, inside the captured
+        # update — instead of on the acting stream before the next policy call (round 2: two launches and ~12 us per step there).
+        # Sound because an update starts only after its agent's last policy call has finished (`acted` event / same stream) and
+        # the next one waits for this update (weights_ev / the stream). actor_lag: weights_updated() packs the alternate set.
+        self._packed_in_part2 = False
+        if self.actor is not None and not self.lag:
+            (w1, b1), (w2, b2) = self.eff
+            self.actor.pack(w1, b1, w2, b2, 0, lazy_two_kernel=True)
+            self._packed_in_part2 = True
 
     def loss(self):
         return torch.mean(self.td * self.w_is)

@@ -393,6 +393,27 @@ class DQNAgent:
         eps = float(self.params.epsilon(self.train_step)) if explore else 0.0
         return q, eps, self.params.seed + 0x9E3779B9, self._draws, self.first_game_id
 
+    def act_for_step(self, observations, explore=True, actions_out=None):
+        """explore() / exploit() for lock-step drivers whose observations already are device tensors: when the policy call runs on
+        the one-kernel actor (hb_actor_fused_act: forward, C51 expectation and epsilon-greedy selection in one launch) this returns
+        the chosen moves (int32 [N], written into `actions_out` when given); otherwise None (then use q_for_step / explore)."""
+        if not self._fused or self.params.resample_noise or not self.use_mfma_actor:
+            return None
+        obs, legal = observations[1]
+        if not isinstance(obs, torch.Tensor) or obs.device != self.device or not isinstance(legal, torch.Tensor):
+            return None
+        fl = self._fused_learner() if self.actor_lag else self._fl
+        if fl is None or fl.actor is None or not fl.actor.takes_fused(obs) or legal.dtype != torch.int8:
+            return None
+        self._wait_for_weights()
+        wset = fl.acting_set()
+        self._draws += 1
+        if self._support0 is None:
+            self._support0 = self.atoms[0].contiguous()
+        eps = float(self.params.epsilon(self.train_step)) if explore else 0.0
+        return fl.actor.act(obs, legal, self._support0, eps, self.params.seed + 0x9E3779B9, self._draws, self.first_game_id, s=wset,
+                            actions_out=actions_out)
+
     # ---- acting (rlax_rainbow.py:277-290) ---------------------------------------------------------------
     @torch.no_grad()
     def exploit(self, observations):

@@ -51,6 +51,17 @@ class HbPackJob(C.Structure):
         (n, C.c_int32) for n in ("k_rows", "n_cols", "w_ld", "group_cols", "k_pad")]
 
 
+class HbCmd(C.Structure):
+    """`hb_cmd` of include/hanabi_hip.h (hb_chain_run)."""
+
+    _fields_ = [("op", C.c_int32), ("var", C.c_int32), ("fvar", C.c_int32), ("cond", C.c_int32), ("stream", C.c_void_p),
+                ("p", C.c_void_p * 16), ("i", C.c_int64 * 10), ("f", C.c_double * 2)]
+
+
+(CMD_WAIT_EVENT, CMD_RECORD_EVENT, CMD_REPLAY_INSERT, CMD_ACTOR_FUSED_ACT, CMD_ENV_STEP_PACKED, CMD_TREE_FILL_RANGE,
+ CMD_PER_SAMPLE_GATHER, CMD_GRAPH_LAUNCH, CMD_PER_UPDATE) = range(1, 10)
+
+
 class HbRule(C.Structure):
     """`hb_rule` of include/hanabi_hip.h."""
 
@@ -150,6 +161,8 @@ SIGNATURES = {
     "hb_actor_fused_sizes": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I32)]),
     "hb_actor_fused_pack": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "hb_actor_fused_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "hb_actor_fused_act": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_float, _U64, _U64, _I64, _P, _P]),
+    "hb_chain_run": (C.c_int, [C.POINTER(HbCmd), _I32, C.POINTER(_I64), C.POINTER(_F64)]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),
 }

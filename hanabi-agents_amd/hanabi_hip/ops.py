@@ -98,9 +98,15 @@ class ActorMFMA:
                            torch.zeros(b2.value // 2, **bf), torch.zeros(nb.value, dtype=torch.float32, device=device))
                           for _ in range(self.n_sets)]
         self._fset_ptrs = [tuple(t.data_ptr() for t in st) for st in self.fsets]
+        self._src = [None] * self.n_sets          # the operands of the last pack() of each set
+        self._two_stale = [False] * self.n_sets   # the two-kernel form's copies of that set are behind them (lazy_two_kernel)
         # one workgroup owns 128 rows from start to end, so below ~one workgroup per two CUs the two-kernel form (more, smaller
         # workgroups) is quicker: measured 58 vs 45 us at 4 096 rows, 56 vs 48 at 7 000, equal at 16 384, 49 vs 69 at 32 768
         self.fused_min_rows = int(os.environ.get("HB_ACTOR_FUSED_MIN_ROWS", "16385"))
+
+    def takes_fused(self, obs):
+        """True when a policy call on `obs` runs on the one-kernel form (bit rows, enough of them)."""
+        return self.fused and obs.dtype == torch.int32 and obs.shape[0] >= self.fused_min_rows and self.n_actions <= 64
 
     def state_tensors(self):
         """Every packed weight copy of every set (checkpoints: with actor_lag the acting set is state of its own)."""
@@ -110,9 +116,24 @@ class ActorMFMA:
     def supports(obs_len, hidden, n_atoms, k_pad, dtype):
         return dtype == torch.bfloat16 and k_pad % 64 == 0 and hidden % 256 == 0 and 2 <= n_atoms <= 256
 
-    def pack(self, w1, b1, w2, b2, s=0):
+    def pack(self, w1, b1, w2, b2, s=0, lazy_two_kernel=False):
         """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K];
-        s: the weight set written."""
+        s: the weight set written. One launch for the one-kernel form's fragment-major copies; the transposed copies of the
+        two-kernel form in a second launch — or, with lazy_two_kernel (only sound when the sources still hold the SAME weights
+        whenever that form is next used: the synchronous agent's persistent `eff` operands), not until a policy call takes it."""
+        self._src[s] = (w1, b1, w2, b2)
+        if self.fused:
+            f = self._fset_ptrs[s]
+            K.check(K.lib().hb_actor_fused_pack(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+                                                self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
+                                                K.current_stream()))
+        if lazy_two_kernel and self.fused:
+            self._two_stale[s] = True
+        else:
+            self._pack_two(s)
+
+    def _pack_two(self, s):
+        w1, b1, w2, b2 = self._src[s]
         key = (s, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w1.stride(0), w2.stride(0))
         jobs = self._jobs.get(key)
         if jobs is None:   # (the learner packs the same persistent operands after every update: build the job table once)
@@ -127,11 +148,7 @@ class ActorMFMA:
             if len(self._jobs) < 16:
                 self._jobs[key] = jobs
         K.check(K.lib().hb_actor_pack_weights(jobs, 2, K.current_stream()))   # both layers in one launch
-        if self.fused:
-            f = self._fset_ptrs[s]
-            K.check(K.lib().hb_actor_fused_pack(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
-                                                self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
-                                                K.current_stream()))
+        self._two_stale[s] = False
 
     def q_values(self, obs, support, s=0):
         """The two GEMMs of a policy call without the selection: q [N, A] fp32 (persistent buffer). For callers that fuse the
@@ -158,12 +175,14 @@ class ActorMFMA:
             K.check(K.lib().hb_actor_fused_q(c[0], n, self.obs_len, f[0], f[1], f[2], f[3], sp, self.hidden, self.n_actions,
                                              self.n_atoms, qp, st))
             return self.q
+        if self._two_stale[s]:
+            self._pack_two(s)
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
         K.check(hidden(c[0], n, self.obs_len, w1p, self.k_pad, b1p, self.hidden, hp, st))
         K.check(qfn(hp, n, self.hidden, w2p, b2p, sp, self.n_actions, self.n_atoms, qp, st))
         return self.q
 
-    def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0, s=0):
+    def act(self, obs, legal, support, epsilon, seed, draw, first_game_id=0, s=0, actions_out=None):
         n = obs.shape[0]
         packed = obs.dtype == torch.int32
         assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
@@ -173,15 +192,17 @@ class ActorMFMA:
             self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
             self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
-        actions = torch.empty(n, dtype=torch.int32, device=obs.device)
-        if self.fused and packed and n >= self.fused_min_rows:
+        actions = actions_out if actions_out is not None else torch.empty(n, dtype=torch.int32, device=obs.device)
+        if self.fused and packed and n >= self.fused_min_rows and self.n_actions <= 64:
+            # ONE launch: forward + C51 expectation + the epsilon-greedy selection on the rows each workgroup has just written
             f = self._fset_ptrs[s]
-            st = K.current_stream()
-            K.check(K.lib().hb_actor_fused_q(obs.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3], support.data_ptr(), self.hidden,
-                                             self.n_actions, self.n_atoms, self.q.data_ptr(), st))
-            K.check(K.lib().hb_policy_select(self.q.data_ptr(), legal.data_ptr(), n, self.n_actions, float(epsilon), int(seed),
-                                             int(draw), int(first_game_id), actions.data_ptr(), st))
+            K.check(K.lib().hb_actor_fused_act(obs.data_ptr(), legal.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3],
+                                               support.data_ptr(), self.hidden, self.n_actions, self.n_atoms, self.q.data_ptr(),
+                                               float(epsilon), int(seed), int(draw), int(first_game_id), actions.data_ptr(),
+                                               K.current_stream()))
             return actions
+        if self._two_stale[s]:
+            self._pack_two(s)
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
         K.check(K.lib().hb_actor_act(obs.data_ptr(), 1 if packed else 0, legal.data_ptr(), n, self.obs_len, w1p, self.k_pad, b1p,
                                      self.hidden, self.h.data_ptr(), w2p, b2p, support.data_ptr(), self.n_actions, self.n_atoms,

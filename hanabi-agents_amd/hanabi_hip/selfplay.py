@@ -24,7 +24,8 @@ from . import _capi as K
 
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
-                 learner_stream=True, learner_priority=-1, stream_per_agent=None, fuse_select=True, split_update=True):
+                 learner_stream=True, learner_priority=-1, stream_per_agent=None, fuse_select=True, split_update=True,
+                 native_chain=True):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -79,11 +80,87 @@ class SelfPlaySession:
         self.grad_steps = 0
         self._inflight = None  # agent whose update_begin() has run but not its update_finish() (data-parallel overlap)
         self._stats0 = env.stats()
+        # One host call per step (hb_chain_run, csrc/chain.hip): once a seat's step has run through the ordinary path below and
+        # every buffer, event and the update's graph exist, the same launches are replayed from a command array filled once.
+        self.native_chain = bool(native_chain) and env.device.type == "cuda"
+        self._chains = {}        # seat -> _Chain
+        self.native_steps = 0
+
+    # ---- one host call per step ----------------------------------------------------------------------------------------------
+    def _chain_for(self, seat, agent, train, raw):
+        """The seat's command array, built when (and rebuilt if) the conditions of the replay hold; None -> ordinary path.
+        Covered: packed env, one-kernel actor, synchronous agent with split update on its own learner stream, prioritized
+        replay, the whole update captured in ONE graph (single rank), one update per step."""
+        env = self.env
+        if not (self.native_chain and train and self.learner_stream is not None and self.fuse_select and self.updates_per_step == 1
+                and seat in self.train_seats and self.t >= env.players and getattr(env, "packed", False)):
+            return None
+        if not (hasattr(agent, "_fl") and getattr(agent, "split_update", False) and not getattr(agent, "actor_lag", 0)):
+            return None
+        fl, p = agent._fl, agent.params
+        if (fl is None or fl.actor is None or fl.actor_stale or not p.use_priority or p.resample_noise or not agent.use_mfma_actor
+                or agent._graph1 is None or agent._graph2 is not None or agent._pending is not None or agent._pending_fills
+                or agent._dense_call is None or fl._sg_call is None or agent.gathered_ev is None or agent.weights_ev is None
+                or seat not in self._acted_ev or not self._ready(agent) or not fl.actor.takes_fused(env.net_obs)):
+            return None
+        if agent.train_step % p.target_update_period == 0:
+            return None   # (this update is followed by a target sync: torch copies, ordinary path)
+        buf = agent.experience
+        ch = self._chains.get(seat)
+        ls = self._learner_stream_of(agent)
+        key = (raw, ls.cuda_stream, agent._dense_call[0], fl._sg_call[0], fl._sg_call[1], id(agent._graph1), buf.rows_per_insert,
+               self.last_actions[seat].data_ptr(), self._act_buf[seat].data_ptr(), agent._g_idx.data_ptr(), agent._g_prios.data_ptr())
+        if ch is None or ch.key != key:
+            ch = self._chains[seat] = _Chain(self, seat, agent, raw, ls.cuda_stream, key)
+        return ch
+
+    def _native_step(self, ch, seat, agent, explore):
+        env, buf, fl = self.env, agent.experience, agent._fl
+        n = env.n
+        vi, vf = ch.vi, ch.vf
+        start = buf.oldest_entry
+        agent._draws += 1
+        vi[0], vi[1], vi[2], vi[3] = start, agent._draws, start, n
+        vi[4] = 1 if (self._update_done.pop(id(agent), None) is not None and agent.gathered_ev.recorded) else 0
+        vi[5] = 1 if agent.weights_ev.recorded else 0
+        vf[0] = float(agent.params.epsilon(agent.train_step)) if explore else 0.0
+        buf._advance(n)
+        # device scalars the update reads: refreshed (on the learner stream, as update_begin does) only when they change
+        beta = float(agent.params.beta_is(agent.train_step))
+        if buf._synced != (buf.size, buf.oldest_entry) or beta != agent._beta_host:
+            K.set_stream(ch.ls)
+            try:
+                buf.sync_size()
+                if beta != agent._beta_host:
+                    agent._beta.fill_(beta)
+                    agent._beta_host = beta
+            finally:
+                K.set_stream(self._main)
+        K.check(ch.run(ch.cmds, ch.count, vi, vf))
+        agent.gathered_ev.recorded = agent.weights_ev.recorded = True
+        self._acted_ev[seat].recorded = True
+        env._obs_stale = True
+        self.last_actions[seat] = self._act_buf[seat]
+        agent._eff_cache = None
+        fl.weights_updated()
+        agent.train_step += 1
+        self._update_done[id(agent)] = ch.done
+        self.env_steps += n
+        self.grad_steps += 1
+        self.native_steps += 1
+        self.t += 1
 
     def step(self, train=True, explore=True):
         env = self.env
         seat = self.t % env.players
         agent = self.agents[seat]
+        if self.native_chain and self.learner_stream is not None:
+            raw = K.current_stream().value
+            if raw != self._main_raw:
+                self._main, self._main_raw = torch.cuda.current_stream(), raw
+            ch = self._chain_for(seat, agent, train, raw)
+            if ch is not None:
+                return self._native_step(ch, seat, agent, explore)
         main = None
         if self.learner_stream is not None:
             raw = K.current_stream().value  # (torch.cuda.current_stream() costs ~8 us of Python: look it up only when it changed)
@@ -109,8 +186,17 @@ class SelfPlaySession:
             agent.add_experience(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
         else:
             agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
-        sel = agent.q_for_step(observations, explore) if (self.fuse_select and hasattr(agent, "q_for_step")) else None
-        if sel is not None:
+        actions = None
+        if self.fuse_select and hasattr(agent, "act_for_step"):
+            # one-kernel actor: forward + selection in ONE launch; the env kernel then takes plain moves (4 B per game instead of
+            # the 100-byte q and legal rows the selection fused into the env step reads)
+            actions = agent.act_for_step(observations, explore, actions_out=self._act_buf[seat])
+        sel = None
+        if actions is None and self.fuse_select and hasattr(agent, "q_for_step"):
+            sel = agent.q_for_step(observations, explore)
+        if actions is not None:
+            env.step(actions)
+        elif sel is not None:
             # the network's q values go straight into the env kernel, which picks each game's move by the agent's own rule and
             # draws (identical actions) and applies it: no selection launch, no round trip of the actions
             actions = self._act_buf[seat]
@@ -276,3 +362,69 @@ class SelfPlaySession:
         ep, sc = self.env.stats()
         ep, sc = ep - self._stats0[0], sc - self._stats0[1]
         return sc / ep if ep else float("nan")
+
+
+class _Chain:
+    """One seat's step as an hb_cmd array (include/hanabi_hip.h, hb_chain_run): acting stream — wait (rings read), replay insert,
+    wait (weights written), policy kernel with the selection inside, env step, record `acted`; learner stream — wait `acted`, tree
+    leaves of the inserted rows, sample + gather, record `gathered`, the captured update, record `weights`, priority write-back.
+    The same launches in the same order on the same streams as SelfPlaySession.step's ordinary path."""
+
+    def __init__(self, session, seat, agent, raw, lraw, key):
+        import ctypes as C
+
+        env, buf, fl = session.env, agent.experience, agent._fl
+        self.key, self.ls = key, session._learner_stream_of(agent)
+        cmds = (K.HbCmd * 13)()
+        A, Ls = C.c_void_p(raw), C.c_void_p(lraw)
+
+        def put(k, op, stream, ptrs=(), ints=(), floats=(), var=-1, fvar=-1, cond=-1):
+            c = cmds[k]
+            c.op, c.var, c.fvar, c.cond, c.stream = op, var, fvar, cond, stream
+            for j, v in enumerate(ptrs):
+                c.p[j] = v.value if isinstance(v, C.c_void_p) else v
+            for j, v in enumerate(ints):
+                c.i[j] = int(v)
+            for j, v in enumerate(floats):
+                c.f[j] = float(v)
+
+        acted = session._acted_ev[seat]
+        done = session._done_ev.get(id(agent))
+        if done is None:
+            done = session._done_ev[id(agent)] = K.Event()
+        self.done = done
+        ins = agent._dense_call[3]      # hb_replay_insert's fixed arguments: 12 pointers, n, row bytes, n_actions, capacity
+        put(0, K.CMD_WAIT_EVENT, A, [agent.gathered_ev.h], cond=4)
+        put(1, K.CMD_REPLAY_INSERT, A, ins[:12], ins[12:16], var=0)
+        put(2, K.CMD_WAIT_EVENT, A, [agent.weights_ev.h], cond=5)
+        act = fl.actor
+        f = act._fset_ptrs[0]
+        if agent._support0 is None:
+            agent._support0 = agent.atoms[0].contiguous()
+        put(3, K.CMD_ACTOR_FUSED_ACT, A,
+            [env.net_obs.data_ptr(), env.legal.data_ptr(), f[0], f[1], f[2], f[3], agent._support0.data_ptr(), act.q.data_ptr(),
+             session._act_buf[seat].data_ptr()],
+            [env.n, act.obs_len, act.hidden, act.n_actions, act.n_atoms, agent.params.seed + 0x9E3779B9, agent.first_game_id],
+            var=1, fvar=0)
+        put(4, K.CMD_ENV_STEP_PACKED, A,
+            [env.h, session._act_buf[seat].data_ptr(), env.obs_bits.data_ptr(), None, env.legal.data_ptr(), env.reward.data_ptr(),
+             env.terminal.data_ptr(), env.agent_reward.data_ptr(), env.agent_step_type.data_ptr(), env.score.data_ptr()])
+        put(5, K.CMD_RECORD_EVENT, A, [acted.h])
+        put(6, K.CMD_WAIT_EVENT, Ls, [acted.h])
+        put(7, K.CMD_TREE_FILL_RANGE, Ls, [buf.sum_tree.h, buf._max_priority.data_ptr()], var=2)
+        g = fl._sg_call[3]              # hb_per_sample_gather's arguments in declaration order
+        put(8, K.CMD_PER_SAMPLE_GATHER, Ls,
+            [g[0], g[2], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[13], g[16], g[17], g[18], g[19], g[24]],
+            [g[1], g[3], g[11], g[12], g[14], g[15], g[20], g[22], g[23]], [g[21]])
+        put(9, K.CMD_RECORD_EVENT, Ls, [agent.gathered_ev.h])
+        put(10, K.CMD_GRAPH_LAUNCH, Ls, [agent._graph1.raw_cuda_graph_exec()])
+        put(11, K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
+        prios = agent._g_prios
+        assert prios.dtype == torch.float32 and prios.is_contiguous() and agent._g_idx.dtype == torch.int64
+        put(12, K.CMD_PER_UPDATE, Ls,
+            [buf.sum_tree.h, agent._g_idx.data_ptr(), prios.data_ptr(), buf._max_priority.data_ptr(), buf._min_priority.data_ptr()],
+            [agent._g_idx.numel()], [buf.alpha])
+        self.cmds, self.count = cmds, 13
+        self.vi = (C.c_int64 * 8)()
+        self.vf = (C.c_double * 2)()
+        self.run = K.lib().hb_chain_run

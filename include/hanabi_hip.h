@@ -554,7 +554,9 @@ int hb_actor_act(const void* obs_dev, int32_t obs_is_packed, const int8_t* legal
  *   hb_actor_fused_sizes      bytes of the two fragment-major weight copies and floats of the physical-order output bias
  *   hb_actor_fused_pack       effective weights (bf16 row-major W1 [>= obs_len, 512] / W2 [512, >= A * 51], bf16 biases) -> the
  *                             copies the kernel streams: one launch; call after every weight change
- *   hb_actor_fused_q          q [n_rows, n_actions] fp32 from obs_bits [n_rows, ceil(obs_len / 32)] u32                      */
+ *   hb_actor_fused_q          q [n_rows, n_actions] fp32 from obs_bits [n_rows, ceil(obs_len / 32)] u32
+ *   hb_actor_fused_act        the same launch followed, inside the kernel, by hb_policy_select's rule on the rows each workgroup
+ *                             has just written (same Philox draws, same tie rule: identical actions); n_actions <= 64           */
 int hb_actor_fused_supported(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms);
 int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, int64_t* w1f_bytes,
                          int64_t* w2f_bytes, int32_t* b2f_floats);
@@ -564,6 +566,43 @@ int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, c
 int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                      const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
                      int32_t n_atoms, float* q_dev, void* stream);
+int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev,
+                       const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
+                       int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
+                       int64_t first_game_id, int32_t* actions_dev, void* stream);
+
+/* ---- One host call per step: hb_chain_run (csrc/chain.hip, round 3) ------------------------------------------------------
+ * The session that drives DQNAgent (rlax_rainbow.py:277-339: explore / add_experience / update once per env step) issues ~25
+ * launches, event waits and event records per step. A host fills an array of hb_cmd ONCE with every pointer, size and stream of
+ * one step and then replays it with one call per step, passing what changes (ring position, draw counter, epsilon ...) in two
+ * small variable arrays. Each command forwards to the function of the same name above with
+ *   p[] / i[] / f[]  its fixed arguments in declaration order (pointers / integers / floating point),
+ *   var, fvar        index into vars_i / vars_f of its per-run arguments (-1: none),
+ *   cond             index into vars_i of a run / skip switch (-1: always run), stream the hipStream_t it is issued on.
+ * Per-run arguments: HB_CMD_REPLAY_INSERT vars_i[var] = start; HB_CMD_ACTOR_FUSED_ACT vars_i[var] = draw, vars_f[fvar] = epsilon
+ * (i[5] = seed, i[6] = first_game_id); HB_CMD_TREE_FILL_RANGE vars_i[var], vars_i[var + 1] = start, n (n = 0: skipped);
+ * HB_CMD_GRAPH_LAUNCH p[0] = a hipGraphExec_t of the caller (the captured learner update); events are hb_event_create handles.
+ * Nothing is computed here: results are those of the individual calls.                                                        */
+enum {
+  HB_CMD_WAIT_EVENT = 1,       /* hb_stream_wait_event(stream, p[0]) */
+  HB_CMD_RECORD_EVENT = 2,     /* hb_event_record(p[0], stream) */
+  HB_CMD_REPLAY_INSERT = 3,    /* p[0..11], i[0..3] = n, obs_len (bytes per row), n_actions, capacity */
+  HB_CMD_ACTOR_FUSED_ACT = 4,  /* p = obs_bits, legal, w1f, b1f, w2f, b2f, support, q, actions; i = n_rows, obs_len, hidden, A, atoms, seed, first_gid */
+  HB_CMD_ENV_STEP_PACKED = 5,  /* p = env, actions, obs_bits, obs, legal, reward, terminal, agent_reward, agent_step_type, score */
+  HB_CMD_TREE_FILL_RANGE = 6,  /* p = tree, value */
+  HB_CMD_PER_SAMPLE_GATHER = 7,/* p = tree, counter, idx, prob, obs_tm1, obs_t, act, rew, term, x, act_out, rew_out, term_out, disc_out, size_wp;
+                                  i = seed, batch, obs_len, packed, x_dtype, x_ld, n_step, capacity, rows_per_insert; f[0] = gamma */
+  HB_CMD_GRAPH_LAUNCH = 8,     /* p = hipGraphExec_t */
+  HB_CMD_PER_UPDATE = 9        /* p = tree, idx, td, max_prio, min_prio; i[0] = n; f[0] = alpha */
+};
+typedef struct hb_cmd {
+  int32_t op, var, fvar, cond;
+  void* stream;
+  void* p[16];
+  int64_t i[10];
+  double f[2];
+} hb_cmd;
+int hb_chain_run(const hb_cmd* cmds, int32_t count, const int64_t* vars_i, const double* vars_f);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,31 @@ def test_fused_equals_two_kernel_form_and_selects_legal_moves():
         assert torch.equal(masked.gather(1, a.long()[:, None])[:, 0], masked.max(1).values)
 
 
+@pytest.mark.parametrize("shape,n", [("full2", 32768), ("full5", 900), ("small2", 130)])
+def test_fused_act_selects_like_hb_policy_select(shape, n):
+    """hb_actor_fused_act (selection inside the kernel, on the q rows the workgroup has just written) == hb_actor_fused_q followed
+    by hb_policy_select: identical q, identical actions (same Philox draws, same tie rule), greedy and with exploration."""
+    import torch
+
+    from hanabi_hip import _capi as K
+
+    obs_len, n_act = SHAPES[shape]
+    act, obs, bits, w, support = _setup(obs_len, n_act, n, seed=n)
+    g = torch.Generator(device="cuda").manual_seed(n + 1)
+    for rep, eps in enumerate((0.0, 0.3, 1.0)):
+        legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.5).to(torch.int8)
+        legal[:, rep % n_act] = 1
+        a_f = act.act(bits, legal, support, eps, 77, 100 + rep, 4096).clone()
+        q_f = act.q.clone()
+        q_s = act.q_values(bits, support).clone()
+        a_s = torch.empty(n, dtype=torch.int32, device="cuda")
+        K.check(K.lib().hb_policy_select(q_s.data_ptr(), legal.data_ptr(), n, n_act, eps, 77, 100 + rep, 4096, a_s.data_ptr(),
+                                         K.current_stream()))
+        assert torch.equal(q_f, q_s)
+        assert torch.equal(a_f, a_s), f"eps {eps}: {(a_f != a_s).sum().item()} actions differ"
+        assert bool(legal.gather(1, a_f.long()[:, None]).all())
+
+
 def _logit_of_column(col, n_actions, n_pass):
     """Python restatement of the packer's physical column order (csrc/actor_fused.hip, fused_logit)."""
     slot, c = col >> 6, col & 63

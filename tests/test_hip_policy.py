@@ -164,7 +164,7 @@ def test_graphed_uniform_replay_samples_the_same_batches_as_eager():
 
     n, obs_len, n_act = 512, 658, 20
     params = RlaxRainbowParams(distributional=False, use_priority=False, train_batch_size=64, experience_buffer_size=512,
-                               target_update_period=4, compute_dtype="bfloat16")
+                               target_update_period=4, compute_dtype="float32")
     agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=g) for g in (True, False)]
     g = torch.Generator(device="cuda").manual_seed(2)
     o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)

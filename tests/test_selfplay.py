@@ -164,3 +164,104 @@ def test_selection_fused_into_the_env_step_gives_identical_training(lag):
         assert torch.equal(x, y), f"actions differ at step {k}"
     for k, (x, y) in enumerate(zip(out_a, out_b)):
         assert torch.equal(x, y), f"item {k} differs"
+
+
+@pytest.mark.parametrize("lag", [0, 1])
+def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
+    """The configuration bench.py times — Hanabi-Full 2 players, bit-packed observation rows end to end, [512] net in bf16 on the
+    one-kernel actor (selection inside the kernel), split update on per-agent learner streams, HIP graphs, one host call per step
+    (hb_chain_run) — replayed move by move on the CPU oracle: every transition that reached the two replay rings equals the
+    oracle's (observations, legal masks, per-seat rewards, terminals), synchronous actor and actor_lag = 1."""
+    import torch
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+    from oracle import oracle_py as O
+
+    monkeypatch.setenv("HB_ACTOR_FUSED_MIN_ROWS", "0")     # (the one-kernel actor at this test's 2 048 rows)
+    n, steps = 2048, 26
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=3, packed=True)
+    orc = O.OracleEnv(O.make_config("Hanabi-Full", 2, flags), n, seed=3)
+    params = RlaxRainbowParams(train_batch_size=256, experience_buffer_size=n * 16, layers=[512], mask_terminal=True,
+                               compute_dtype="bfloat16", packed_obs=True, actor_lag=lag, target_update_period=5)
+    agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
+              for s in (1, 2)]
+    sess = SelfPlaySession(env, agents)      # default options: what bench.py runs
+    assert sess.fuse_select and sess.learner_stream is not None
+    last_obs, last_act, want = [None, None], [None, None], [[], []]
+    out = orc.observe()
+    for t in range(steps):
+        seat = t % 2
+        if last_obs[seat] is not None:
+            want[seat].append((last_obs[seat], last_act[seat], out["agent_reward"].copy(), out["obs"].copy(), out["legal"].copy(),
+                               out["agent_step_type"] == 2))
+        last_obs[seat] = out["obs"].copy()
+        sess.step()
+        a = sess.last_actions[seat].cpu().numpy()
+        assert (out["legal"][np.arange(n), a] == 1).all(), "agent picked an illegal move"
+        last_act[seat] = a.copy()
+        out = orc.step(a)
+        assert np.array_equal(env.obs.cpu().numpy(), out["obs"])
+    sess.flush()
+    torch.cuda.synchronize()
+    fl = agents[0]._fl
+    assert fl.actor is not None and fl.actor.fused and all(a.split_update for a in agents) and sess._stream_per_agent
+    assert agents[0]._graph1 is not None and sess.grad_steps >= steps - 4
+    if lag == 0:
+        assert sess.native_steps >= steps - 10, sess.native_steps     # most steps went through hb_chain_run
+    assert env.illegal_count() == 0
+    for seat in (0, 1):
+        buf = agents[seat].experience
+        k = len(want[seat])
+        assert buf.size == k * n
+        tr = buf[np.arange(buf.size)]
+        for j, (o1, act, rew, o2, lg, term) in enumerate(want[seat]):
+            sl = slice(j * n, (j + 1) * n)
+            assert np.array_equal(tr.observation_tm1[sl], o1) and np.array_equal(tr.observation_t[sl], o2)
+            assert np.array_equal(tr.action_tm1[sl, 0], act) and np.array_equal(tr.reward_t[sl, 0], rew)
+            assert np.array_equal(tr.legal_moves_t[sl], lg) and np.array_equal(tr.terminal_t[sl, 0], term)
+
+
+def test_one_host_call_per_step_gives_identical_training(monkeypatch):
+    """SelfPlaySession(native_chain=True): the step replayed from an hb_cmd array by ONE hb_chain_run call (csrc/chain.hip) against
+    the ordinary path's ~25 host calls: same moves every step, identical weights, moments, replay rings, sum trees and env rows."""
+    import torch
+
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    monkeypatch.setenv("HB_ACTOR_FUSED_MIN_ROWS", "0")
+
+    def run(native, n_step):
+        torch.manual_seed(0)
+        flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+        env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=1024, seed=5, packed=True)
+        params = RlaxRainbowParams(train_batch_size=128, experience_buffer_size=1024 * 8, mask_terminal=True, target_update_period=6,
+                                   compute_dtype="bfloat16", packed_obs=True, layers=[512], learning_rate=0.01, n_step=n_step)
+        agents = [DQNAgent(ObservationSpec((1024, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
+                  for s in (1, 2)]
+        sess = SelfPlaySession(env, agents, native_chain=native)
+        acts = []
+        for _ in range(44):          # (the ring wraps: 8 inserts per agent fill it)
+            sess.step()
+            acts.append(sess.last_actions[(sess.t - 1) % 2].clone())
+        sess.flush()
+        torch.cuda.synchronize()
+        assert (sess.native_steps > 20) == native, sess.native_steps
+        out = [env.export_state(), env.obs_bits.clone()]
+        for a in agents:
+            out += [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]), a.experience.sum_tree.nodes(),
+                    a.experience._obs_t_buf.clone(), a.experience._act_tm1_buf.clone(), a._fl.step.clone()]
+            out += [t.clone() for pair in a._fl.state.values() for t in pair]
+        return acts, out, sess.grad_steps
+
+    for n_step in (1, 3):
+        (acts_a, out_a, g_a), (acts_b, out_b, g_b) = run(False, n_step), run(True, n_step)
+        assert g_a == g_b
+        for k, (x, y) in enumerate(zip(acts_a, acts_b)):
+            assert torch.equal(x, y), f"n_step {n_step}: actions differ at step {k}"
+        for k, (x, y) in enumerate(zip(out_a, out_b)):
+            assert torch.equal(x, y), f"n_step {n_step}: item {k} differs"
