@@ -111,6 +111,11 @@ class SelfPlaySession:
         key = (raw, ls.cuda_stream, agent._dense_call[0], fl._sg_call[0], fl._sg_call[1], id(agent._graph1), buf.rows_per_insert,
                self.last_actions[seat].data_ptr(), self._act_buf[seat].data_ptr(), agent._g_idx.data_ptr(), agent._g_prios.data_ptr())
         if ch is None or ch.key != key:
+            # the cached insert call must be the one the ordinary path would make NOW (same seven operands, add_experience_dense)
+            now = (env.net_obs.data_ptr(), env.legal.data_ptr(), self.last_actions[seat].data_ptr(), env.agent_reward.data_ptr(),
+                   env.agent_step_type.data_ptr(), agent.last_obs.data_ptr(), buf._obs_t_buf.data_ptr())
+            if agent._dense_call[0] != now or agent._dense_call[1] != env.n or self.last_actions[seat] is not self._act_buf[seat]:
+                return None
             ch = self._chains[seat] = _Chain(self, seat, agent, raw, ls.cuda_stream, key)
         return ch
 
