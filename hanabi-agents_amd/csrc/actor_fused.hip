@@ -47,7 +47,7 @@ constexpr int S2 = FH / 32;             // K steps of layer 2
 constexpr int LUT_BYTES = 65536;        // 256 byte values x 16 slots x 16 B
 constexpr int H_BYTES = FM * FH * 2;    // 131 072
 constexpr int FRAG_FLOATS = 3 * 8 * FM; // one buffer of quarter-action triples: [max | sum | weighted sum][wave][row] fp32 (12 KiB)
-constexpr int LDS_TOTAL = H_BYTES + 32768;            // 163 840 = all of a CU's LDS
+constexpr int LDS_TOTAL = H_BYTES + 2 * FRAG_FLOATS * 4;   // 155 648: 8 KiB of the CU's 160 stay free for the learner's small kernels (tree fill, sample + gather, transposer), which run beside this kernel on another stream
 constexpr float NEG_BIG = -1e30f;
 
 struct FusedArgs {
@@ -130,7 +130,8 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 
 __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_TOTAL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: everything derived from it lives in scalar registers)
   const int r = lane & 15, qd = lane >> 4;
   const long long row0 = static_cast<long long>(blockIdx.x) * FM;
   const int s1 = a.s1, G = (s1 + 3) >> 2;
@@ -259,17 +260,6 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
   // =========================== layer 2 in passes of 512 physical columns + the C51 expectation from the accumulators
   const int n_pass = a.n_pass, A = a.n_actions;
   const int full_cap = 8 * n_pass;
-  // per-lane support values, in the register pairs the packed sums use. Whole action: register (n, j), n < 3, holds atom
-  // 4 (4 n + j) + q; register (3, 0) holds atom 48 + q in lanes q < 3. Quarter f: registers (3, 1..3) hold atom 13 f + 4 (j - 1) + q,
-  // register (3, 0) of lanes q == 3 atom 13 f + 12.
-  auto sup_at = [&](int k) { return a.support[k < FK ? k : FK - 1]; };
-  f32x2 supF[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) supF[i] = f32x2{sup_at(4 * (2 * i) + qd), sup_at(4 * (2 * i + 1) + qd)};
-  const float supF12 = sup_at(48 + qd);
-  const int fq = wave & 3;   // which quarter of its extra action this wavefront holds
-  const f32x2 supZa = f32x2{sup_at(13 * fq + qd), sup_at(13 * fq + 4 + qd)};
-  const f32x2 supZb = f32x2{sup_at(13 * fq + 8 + qd), sup_at(13 * fq + 12)};
   constexpr float LOG2E = 1.44269504088896340736f;
   const unsigned char* hrow = lds + r * 1024;
 
@@ -285,20 +275,30 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
       }
     }
     const uint4* wp = w2p + static_cast<long long>(p) * S2 * 2048;
+// The B operands (rows of H) are read four row tiles at a time and the second four only once the first four's MFMAs have been
+// issued (sched_barrier): 16 fragment registers instead of 32. The LDS latency this exposes is covered by the SIMD's other
+// wavefront; what it buys is a kernel of 232 registers, i.e. 48 free per SIMD lane beside its two wavefronts: the learner's
+// forward kernels (36-47 registers) then run on the same CUs while this kernel holds them (DESIGN: co-residency).
+#define HB_L2_HALF(S, WCUR, M0)                                                                                \
+  {                                                                                                            \
+    bf16x8 xf[4];                                                                                              \
+    const int ch = ((4 * (S) + qd) ^ r) << 4;                                                                  \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(hrow + ((M0) + m) * 16384 + ch); \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                            \
+      const bf16x8 wf = as_frag(WCUR[n]);                                                                      \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                            \
+        acc[n][(M0) + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[n][(M0) + m], 0, 0, 0);      \
+    }                                                                                                          \
+  }
 #define HB_L2_STEP(S, WCUR, WNXT, HAVE_NEXT)                                                                   \
   {                                                                                                            \
     if (HAVE_NEXT) {                                                                                           \
       _Pragma("unroll") for (int n = 0; n < 4; ++n) WNXT[n] = wp[((S) + 1) * 2048 + n * 64];                    \
     }                                                                                                          \
     asm volatile("" ::: "memory");                                                                             \
-    bf16x8 xf[8];                                                                                              \
-    const int ch = ((4 * (S) + qd) ^ r) << 4;                                                                  \
-    _Pragma("unroll") for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(hrow + m * 16384 + ch); \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                            \
-      const bf16x8 wf = as_frag(WCUR[n]);                                                                      \
-      _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                            \
-        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[n][m], 0, 0, 0);                    \
-    }                                                                                                          \
+    HB_L2_HALF(S, WCUR, 0)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    HB_L2_HALF(S, WCUR, 4)                                                                                     \
   }
 #pragma unroll 1
     for (int s = 0; s < S2; s += 2) {
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
       HB_L2_STEP(s + 1, wb, wa, (s + 2 < S2))
     }
 #undef HB_L2_STEP
+#undef HB_L2_HALF
     if (p < 2) HB_FSTAMP(7 + 3 * p);
     // next pass's first weights in flight during the epilogue
     if (p + 1 < n_pass) {
@@ -314,14 +315,30 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     }
 
     // ---- epilogue of slot (p, wave): register (n, j) of lane group q is physical column 16 n + 4 q + j of the slot
+    // (loaded here, per pass, rather than kept across the K loop: 18 registers the loop does not have to carry)
+    // per-lane support values, in the register pairs the packed sums use. Whole action: register (n, j), n < 3, holds atom
+    // 4 (4 n + j) + q; register (3, 0) holds atom 48 + q in lanes q < 3. Quarter f: registers (3, 1..3) hold atom 13 f + 4 (j - 1) + q,
+    // register (3, 0) of lanes q == 3 atom 13 f + 12.
+    auto sup_at = [&](int k) { return a.support[k < FK ? k : FK - 1]; };
+    f32x2 supF[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) supF[i] = f32x2{sup_at(4 * (2 * i) + qd), sup_at(4 * (2 * i + 1) + qd)};
+    const float supF12 = sup_at(48 + qd);
+    const int fq = wave & 3;   // which quarter of its extra action this wavefront holds
+    const f32x2 supZa = f32x2{sup_at(13 * fq + qd), sup_at(13 * fq + 4 + qd)};
+    const f32x2 supZb = f32x2{sup_at(13 * fq + 8 + qd), sup_at(13 * fq + 12)};
     const bool full_ok = slot < A && slot < full_cap;
     float* fb = reinterpret_cast<float*>(lds + H_BYTES) + (p & 1) * FRAG_FLOATS + wave * FM;   // component c: + c * 8 * FM
     // Written STAGE BY STAGE over the 8 row tiles (m is the inner loop everywhere): a wavefront issues in order, and one row
     // tile's softmax is a single dependent chain (max -> swaps -> exp -> sums -> swaps), so consecutive instructions must come
     // from different row tiles to keep the vector pipe busy (row tile after row tile: 9.6 k cycles per pass; see DESIGN).
     const f32x2 L2 = f32x2{LOG2E, LOG2E};
-    float qF[8], zm[8], zs[8], zt[8], vf12[8], vz3[8], nmx[8], nmz[8];
-#define HB_M for (int m = 0; m < 8; ++m)
+    // (two halves of four row tiles: the temporaries of all eight at once cost 16 registers more than the kernel may use if the
+    //  learner's small kernels are to run beside it: 232 registers x 2 wavefronts leave 48 per SIMD lane)
+    hb::static_for<2>([&](auto MH) {
+    constexpr int M0 = 4 * decltype(MH)::value;
+    float qF[4], zm[4], zs[4], zt[4], vf12[4], vz3[4], nmx[4], nmz[4];
+#define HB_M for (int m = 0; m < 4; ++m)
 #define HB_SWAP16(X, OP) { const u32x2 t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(X), __float_as_uint(X), false, false); \
                            X = OP(__uint_as_float(t_.x), __uint_as_float(t_.y)); }
 #define HB_SWAP32(X, OP) { const u32x2 t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false); \
@@ -329,21 +346,21 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
 #define HB_ADD(A_, B_) ((A_) + (B_))
     // register (3, 0) is shared: lanes q < 3 -> atoms 48..50 of the whole action, lanes q == 3 -> the quarter's 13th position
 #pragma unroll
-    HB_M { vf12[m] = qd < 3 ? acc[3][m][0] : NEG_BIG; vz3[m] = qd == 3 ? acc[3][m][0] : NEG_BIG; }
+    HB_M { vf12[m] = qd < 3 ? acc[3][M0 + m][0] : NEG_BIG; vz3[m] = qd == 3 ? acc[3][M0 + m][0] : NEG_BIG; }
 #pragma unroll
-    HB_M nmx[m] = vmax3(acc[0][m][0], acc[0][m][1], acc[0][m][2]);
+    HB_M nmx[m] = vmax3(acc[0][M0 + m][0], acc[0][M0 + m][1], acc[0][M0 + m][2]);
 #pragma unroll
-    HB_M nmx[m] = vmax3(nmx[m], acc[0][m][3], acc[1][m][0]);
+    HB_M nmx[m] = vmax3(nmx[m], acc[0][M0 + m][3], acc[1][M0 + m][0]);
 #pragma unroll
-    HB_M nmx[m] = vmax3(nmx[m], acc[1][m][1], acc[1][m][2]);
+    HB_M nmx[m] = vmax3(nmx[m], acc[1][M0 + m][1], acc[1][M0 + m][2]);
 #pragma unroll
-    HB_M nmx[m] = vmax3(nmx[m], acc[1][m][3], acc[2][m][0]);
+    HB_M nmx[m] = vmax3(nmx[m], acc[1][M0 + m][3], acc[2][M0 + m][0]);
 #pragma unroll
-    HB_M nmx[m] = vmax3(nmx[m], acc[2][m][1], acc[2][m][2]);
+    HB_M nmx[m] = vmax3(nmx[m], acc[2][M0 + m][1], acc[2][M0 + m][2]);
 #pragma unroll
-    HB_M nmx[m] = vmax3(nmx[m], acc[2][m][3], vf12[m]);
+    HB_M nmx[m] = vmax3(nmx[m], acc[2][M0 + m][3], vf12[m]);
 #pragma unroll
-    HB_M nmz[m] = vmax(vmax3(acc[3][m][1], acc[3][m][2], acc[3][m][3]), vz3[m]);
+    HB_M nmz[m] = vmax(vmax3(acc[3][M0 + m][1], acc[3][M0 + m][2], acc[3][M0 + m][3]), vz3[m]);
 #pragma unroll
     HB_M HB_SWAP16(nmx[m], vmax)
 #pragma unroll
@@ -354,17 +371,17 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     HB_M HB_SWAP32(nmz[m], vmax)
 #pragma unroll
     HB_M { nmx[m] *= -LOG2E; nmz[m] *= -LOG2E; }
-    f32x2 s2[8], t2[8];
+    f32x2 s2[4], t2[4];
 #define HB_PAIR_FIRST(N, LO, SUP)                                                                   \
   _Pragma("unroll") HB_M {                                                                          \
-    const f32x2 arg = f32x2{acc[N][m][LO], acc[N][m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
+    const f32x2 arg = f32x2{acc[N][M0 + m][LO], acc[N][M0 + m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
     const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};                                      \
     s2[m] = e;                                                                                      \
     t2[m] = e * SUP;                                                                                \
   }
 #define HB_PAIR(N, LO, SUP)                                                                         \
   _Pragma("unroll") HB_M {                                                                          \
-    const f32x2 arg = f32x2{acc[N][m][LO], acc[N][m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
+    const f32x2 arg = f32x2{acc[N][M0 + m][LO], acc[N][M0 + m][LO + 1]} * L2 + f32x2{nmx[m], nmx[m]};         \
     const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};                                      \
     s2[m] += e;                                                                                     \
     t2[m] += e * SUP;                                                                               \
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     HB_PAIR(2, 2, supF[5])
 #undef HB_PAIR
 #undef HB_PAIR_FIRST
-    float sF[8], tF[8];
+    float sF[4], tF[4];
 #pragma unroll
     HB_M {
       const float e12 = exp2_fast(vf12[m] * LOG2E + nmx[m]);
@@ -387,14 +404,14 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     // the quarter: registers (3, 1), (3, 2) | (3, 3), shared register
 #pragma unroll
     HB_M {
-      const f32x2 arg = f32x2{acc[3][m][1], acc[3][m][2]} * L2 + f32x2{nmz[m], nmz[m]};
+      const f32x2 arg = f32x2{acc[3][M0 + m][1], acc[3][M0 + m][2]} * L2 + f32x2{nmz[m], nmz[m]};
       const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};
       s2[m] = e;
       t2[m] = e * supZa;
     }
 #pragma unroll
     HB_M {
-      const f32x2 arg = f32x2{acc[3][m][3], vz3[m]} * L2 + f32x2{nmz[m], nmz[m]};
+      const f32x2 arg = f32x2{acc[3][M0 + m][3], vz3[m]} * L2 + f32x2{nmz[m], nmz[m]};
       const f32x2 e = f32x2{exp2_fast(arg.x), exp2_fast(arg.y)};
       s2[m] += e;
       t2[m] += e * supZb;
@@ -425,14 +442,16 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
 #undef HB_ADD
     if (qd == 0) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const long long row = row0 + 16 * m + r;
+      for (int m = 0; m < 4; ++m) {
+        const long long row = row0 + 16 * (M0 + m) + r;
         if (full_ok && row < a.m) a.q[row * A + slot] = qF[m];
-        fb[16 * m + r] = zm[m];
-        fb[8 * FM + 16 * m + r] = zs[m];
-        fb[16 * FM + 16 * m + r] = zt[m];
+        fb[16 * (M0 + m) + r] = zm[m];
+        fb[8 * FM + 16 * (M0 + m) + r] = zs[m];
+        fb[16 * FM + 16 * (M0 + m) + r] = zt[m];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    });
     if (p < 2) HB_FSTAMP(8 + 3 * p);
     __syncthreads();
     // ---- the pass's two extra actions: combine their four quarters (wavefronts 4 g .. 4 g + 3). The buffer alternates with the
