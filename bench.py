@@ -18,10 +18,12 @@ move of all the rank's games through the whole hot path:
 
 `value` = env-steps/s over all ranks inside the timed region; grad-steps/s is reported next to it.
 Extra objects on the same JSON line:
-  roofline      the env kernel (the north-star HBM-bound kernel): algorithmic bytes per launch
-                (obs_len + A + 9 + 2*STATE_BYTES = 943 B per game) / its average
-                dispatch duration, measured live on every launch of the timed region with HIP
-                events attached to the dispatch (hb_env_set_profile_events)
+  roofline      the env kernel (the north-star HBM-bound kernel): ALGORITHMIC bytes per launch
+                (obs_len + A + 9 + 2*STATE_BYTES = 943 B per game, the reference's int8
+                interface) / its average dispatch duration, measured live on every launch of the timed
+                region with HIP events attached to the dispatch (hb_env_set_profile_events); the bytes
+                the bit-packed kernel physically moves (369 B per game) and their fraction of the peak
+                are the side key `physical`, the PMC traffic of the same kernel form is `traffic`
   roofline_qnet MFMA side: algorithmic FLOPs of actor forward + learner step / their event time
   cpu_baseline  the CPU oracle (oracle/, a port: the reference's env is not in its tree) on the
                 host cores, bounded sample of the same workload, rank 0 only
@@ -81,6 +83,8 @@ def _parse():
                     help="BASELINE configs[1]: vanilla double-DQN (scalar Q head, rlax_dqn.py:170-205 spec) with uniform replay, "
                          "4 096 games per GPU")
     ap.add_argument("--players", type=int, default=2)
+    ap.add_argument("--n-step", type=int, default=1, help="n-step returns assembled at sample time (SURVEY 8(f)-2; the reference's agent is 1-step)")
+    ap.add_argument("--no-nstep-variant", action="store_true", help="skip the second synchronous measurement with n_step = 3")
     ap.add_argument("--updates-per-step", type=int, default=1)
     ap.add_argument("--compute-dtype", default="bfloat16", choices=list(MFMA_PEAK_TFLOPS))
     ap.add_argument("--games-per-wave", type=int, default=None, help="8/16/32/64; default: the library's choice")
@@ -339,7 +343,7 @@ def main():
     main_stream = None
     if not args.env_only:
         params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=env.packed,
-                                   actor_lag=args.actor_lag)
+                                   actor_lag=args.actor_lag, n_step=args.n_step)
         if args.vanilla:
             params = params._replace(distributional=False, use_priority=False)
         agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions),
@@ -389,6 +393,8 @@ def main():
         a.record()
         b.record()
     grad0 = session.grad_steps if session else 0
+    sel0 = session.select_in_env_steps if session else 0
+    native0 = session.native_steps if session else 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -420,19 +426,20 @@ def main():
 
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev[::args.event_every])
     kernel_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-    # with the agent's selection fused into the kernel (SelfPlaySession.fuse_select) a launch also reads the q row (4 A bytes) and
-    # the acting seat's legal row (A bytes) per game; its 4-byte action is written instead of read
+    # Which form of the kernel the loop ran. Round 3: the one-kernel actor picks the moves itself (hb_actor_fused_act), so the
+    # env kernel takes plain 4-byte actions (hb_env_step_packed); only agents without that actor still have the selection fused
+    # into the env kernel (hb_env_step_select_packed: +4A q and +A legal bytes read per game).
     bytes_alone = bytes_per_step
-    fused_sel = bool(session is not None and session.fuse_select and not args.vanilla)
+    fused_sel = bool(session is not None and session.select_in_env_steps > sel0)
     if fused_sel:
         bytes_per_step = bytes_per_step + 5 * env.num_actions
-    # `achieved` = the bytes THIS kernel form must move per env-step (observation rows as bits when packed; plus the q / legal
-    # rows of the fused selection) x env-steps per launch / launch duration: a physical fraction of the HBM peak. SURVEY §8(d)
-    # prices an env-step at the reference's int8 interface (943 B for 2 players, 1 721 B for 5): that figure is reported beside
-    # it ("reference_accounting"; it can exceed what the packed kernel moves by 2.5x, so it is not the headline fraction) and
-    # the kernel that really writes the int8 layout is measured separately ("int8_form").
-    achieved = n * bytes_per_step / kernel_avg_s / 1e9
-    ref_acc = n * bytes_int8_form / kernel_avg_s / 1e9
+    # `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC bytes per env-step at the reference's interface (int8 observations:
+    # obs_len + A + 9 + 2 x state bytes = 943 B for 2 players, 1 721 B for 5) x env-steps per launch / launch duration. The kernel
+    # the loop runs keeps the observation as bits (84 B instead of 658 B), so what it physically moves is less: `physical` gives
+    # those bytes and their fraction of the HBM peak, `traffic` the PMC-measured bytes of that same kernel form, and the kernel
+    # that really writes the int8 layout is measured separately ("int8_form").
+    achieved = n * bytes_int8_form / kernel_avg_s / 1e9
+    phys = n * bytes_per_step / kernel_avg_s / 1e9
     line = {
         "metric": "env_steps_per_sec",
         "value": world * n * args.steps / dt,
@@ -467,10 +474,11 @@ def main():
                             "drain_and_sync": dt * 1e3 - ev_t0.elapsed_time(ev_main_end)},
         "roofline": {"bound": "hbm", "kernel": "hb::env_kernel (step + legal mask + canonical encoder)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_env_step": bytes_per_step,
-                     "reference_accounting": {"bytes_per_env_step": bytes_int8_form, "achieved": ref_acc, "frac": ref_acc / HBM_PEAK_GBS,
-                                              "note": "SURVEY 8(d): obs_len + A + 9 + 2 x state bytes per env-step, i.e. the reference's "
-                                                      "int8 observation interface, applied to this launch's duration"},
+                     "traffic": None, "bytes_per_env_step": bytes_int8_form,
+                     "accounting": "SURVEY 8(d): obs_len + A + 9 + 2 x state bytes per env-step (the reference's int8 observation "
+                                   "interface) x env-steps per launch / this launch's duration",
+                     "physical": {"bytes_per_env_step": bytes_per_step, "achieved": phys, "frac": phys / HBM_PEAK_GBS,
+                                  "note": "bytes this kernel form really has to move (observation rows leave as bits)"},
                      "observation_form": ("bit-packed u32 rows + the agent's eps-greedy selection from q (hb_env_step_select_packed: "
                                           "+4A q, +A legal bytes read per game)" if fused_sel else
                                           "bit-packed u32 rows (hb_env_step_packed)" if env.packed else "int8 [N, obs_len] (hb_env_step)"),
@@ -478,17 +486,17 @@ def main():
                      "avg_launch_us": kernel_avg_s * 1e6, "median_launch_us": kernel_ms[len(kernel_ms) // 2] * 1e3,
                      "kernel_only_env_steps_per_sec": n / kernel_avg_s},
     }
+    if session is not None:
+        line["host_calls"] = {"steps_through_hb_chain_run": session.native_steps - native0, "of": args.steps,
+                              "note": "steps issued by ONE host call (csrc/chain.hip) instead of ~25"}
     # HBM traffic of the same kernel/config from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE; profiles/): PMC counters cannot be read from inside this process
-    pmc = os.path.join(ROOT, "profiles", "r02", "env_kernel_pmc_traffic_packed.json" if env.packed else "env_kernel_pmc_traffic.json")
-    if not env.packed and not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r01", "env_kernel_pmc_traffic.json")
-    if n == 32768 and args.players == 2 and os.path.exists(pmc):
+    # (one file per kernel form and player count; the form with the selection fused in has its own pass)
+    stem = "env_kernel_pmc_traffic" + ("_select" if fused_sel else "_packed" if env.packed else "") + (f"_{args.players}p" if args.players != 2 else "")
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", r, stem + ".json") for r in ("r03", "r02", "r01")) if os.path.exists(f)), None)
+    if n == 32768 and pmc is not None:
         line["roofline"]["traffic"] = json.load(open(pmc))["per_launch_bytes"]["total"]
-        line["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc, separate passes)"
-        if env.packed:
-            line["roofline"]["traffic_note"] = ("PMC pass of the env-only packed step (hb_env_step_packed: 369 B per env-step, 12.1 MB "
-                                                "per launch algorithmic)")
+        line["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, of the kernel form named in observation_form)"
     if session is not None:
         line["mean_episode_score"] = session.mean_score()
         # the same kernel with the GPU to itself (random-legal policy, no agents): inside the loop it shares the chip with
@@ -506,9 +514,28 @@ def main():
         env.set_profile_events(None, None)
         alone = sorted(a.elapsed_time(b) for a, b in sa[10:])
         alone_s = sum(alone) / len(alone) / 1e3
-        line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_alone / alone_s / 1e9,
-                                          "frac": n * bytes_alone / alone_s / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": bytes_alone,
-                                          "note": "same kernel, env-only stepping after the timed region (50 launches)"}
+        line["roofline"]["standalone"] = {"avg_launch_us": alone_s * 1e6, "achieved": n * bytes_int8_form / alone_s / 1e9,
+                                          "frac": n * bytes_int8_form / alone_s / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": bytes_int8_form,
+                                          "physical": {"bytes_per_env_step": bytes_alone, "achieved": n * bytes_alone / alone_s / 1e9,
+                                                       "frac": n * bytes_alone / alone_s / 1e9 / HBM_PEAK_GBS},
+                                          "note": "same kernel (plain actions in), env-only stepping after the timed region (50 launches)"}
+        # env kernel + the deck-pool refill launch that follows every `refill_period`-th step, amortised per step: stream time of
+        # 60 env-only steps minus the same 60 launches of the random-legal policy kernel alone
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for k in range(60):
+            env.random_legal_actions(4321, 30_000 + k, out=act)
+            env.step(act)
+        e1.record()
+        for k in range(60):
+            env.random_legal_actions(4321, 30_000 + k, out=act)
+        e2.record()
+        torch.cuda.synchronize()
+        per_step_us = (e0.elapsed_time(e1) - e1.elapsed_time(e2)) / 60 * 1e3
+        line["roofline"]["env_plus_refill"] = {"us_per_step": per_step_us, "achieved": n * bytes_int8_form / (per_step_us * 1e-6) / 1e9,
+                                               "frac": n * bytes_int8_form / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                               "note": "stream time per env-only step including hb::refill_kernel (every third step for "
+                                                       "Hanabi-Full) and the launch gaps, same 8(d) accounting"}
         if env.packed:
             # the reference-shaped output of the same kernel (int8 [N, obs_len], SURVEY §8(d)'s 943 B per env-step), env-only
             env8 = hanabi_hip.HanabiEnv(config=env.cfg, n_games=n, seed=1234, first_game_id=rank * n,
@@ -539,6 +566,13 @@ def main():
         session.flush()
         line["async_actor"] = async_variant(args, rank, world, device, n,   # (every rank: it holds collectives)
                                             streams=list(dict.fromkeys(session._lstreams.values())))
+    if (session is not None and not args.vanilla and args.actor_lag == 0 and args.n_step == 1 and not args.no_nstep_variant
+            and env.packed and args.compute_dtype == "bfloat16"):
+        # north_star: "n-step double-DQN loss". The reference's rlax agent is 1-step (the headline); the n-step form it describes
+        # (replay_memory.py:316-345) is timed beside it
+        session.flush()
+        line["n_step_3"] = async_variant(args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
+                                         actor_lag=0, n_step=3)
     if rank == 0 and not args.no_cpu_baseline:
         note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)   # progress on stderr; stdout carries the ONE JSON line
         note(f"timed region done ({dt / args.steps * 1e3:.4f} ms per step); timing the CPU baselines on rank 0")
@@ -549,6 +583,15 @@ def main():
             note("cpu_baseline_learner done")
         line["cpu_baseline_sum_tree"] = sum_tree_baseline(device)
         note("cpu_baseline_sum_tree done")
+    if world > 1 or force_coll:
+        # proof that N ranks on N devices took part: gathered over the job's own process group
+        info = {"rank": rank, "device_index": device.index, "hostname": socket.gethostname(),
+                "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", "")), "name": torch.cuda.get_device_name(device)}
+        gathered = [None] * (world if world > 1 else 1)
+        dist.all_gather_object(gathered, info)
+        ver = getattr(torch.cuda.nccl, "version", lambda: None)()
+        line["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "version": list(ver) if ver else None,
+                        "ranks": gathered, "distinct_devices": len({(g["hostname"], g["uuid"] or g["device_index"]) for g in gathered})}
     if force_coll:
         line["config"]["parallelism"] += " [HB_BENCH_FORCE_COLLECTIVE: one-rank RCCL group, multi-rank update path]"
     if rank == 0:
@@ -559,7 +602,7 @@ def main():
         dist.destroy_process_group()
 
 
-def async_variant(args, rank, world, device, n, streams=None):
+def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_step=None):
     """The same workload with the asynchronous actor (RlaxRainbowParams.actor_lag = 1, one learner stream per
     agent), timed with the same protocol as the headline. Reported BESIDE the headline, which keeps the reference's
     synchronous semantics: here the policy acts on weights that are one update old (tests/test_async_actor.py)."""
@@ -570,7 +613,8 @@ def async_variant(args, rank, world, device, n, streams=None):
     flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
     env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", args.players, flags), n_games=n, seed=1234,
                                first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device, packed=True)
-    params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=True, actor_lag=1)
+    params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=True, actor_lag=actor_lag,
+                               n_step=args.n_step if n_step is None else n_step)
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s),
                        device=device) for s in range(args.players)]
     for a in agents:
@@ -609,11 +653,16 @@ def async_variant(args, rank, world, device, n, streams=None):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    return {"actor_lag": 1, "learner_streams": "one per agent", "ms_per_step": dt / args.steps * 1e3,
-            "env_steps_per_sec": world * n * args.steps / dt, "grad_steps_per_sec": (session.grad_steps - g0) / dt,
-            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
-            "note": "policy acts on the weights of the update before last (one-update staleness, tests/test_async_actor.py); "
-                    "not the headline: the reference's agent is synchronous"}
+    out = {"actor_lag": actor_lag, "n_step": params.n_step, "learner_streams": "one per agent", "ms_per_step": dt / args.steps * 1e3,
+           "env_steps_per_sec": world * n * args.steps / dt, "grad_steps_per_sec": (session.grad_steps - g0) / dt,
+           "host_enqueue_ms_per_step": host_s / args.steps * 1e3}
+    if actor_lag:
+        out["note"] = ("policy acts on the weights of the update before last (one-update staleness, tests/test_async_actor.py); "
+                       "not the headline: the reference's agent is synchronous")
+    else:
+        out["note"] = ("synchronous agent, n-step returns assembled at sample time by walking the ring (hb_per_sample_gather; spec: "
+                       "hanabi_agents/rainbow/replay_memory.py:316-345), same protocol as the headline")
+    return out
 
 
 def qnet_roofline(agent, env, args):
@@ -652,6 +701,8 @@ def qnet_roofline(agent, env, args):
         from hanabi_hip import _capi as K
 
         ac, L, s = fl0.actor, K.lib(), K.current_stream()
+        if ac._two_stale[0]:
+            ac._pack_two(0)   # (the two-kernel form's weight copies are refreshed lazily since round 3)
         obs8, legal8, support = env.net_obs, env.legal, agent.atoms[0].contiguous()
         acts = torch.empty(n, dtype=torch.int32, device=legal8.device)
         hidden_fn = L.hb_actor_hidden_packed if env.packed else L.hb_actor_hidden
@@ -663,6 +714,14 @@ def qnet_roofline(agent, env, args):
             "hb_policy_select": lambda: L.hb_policy_select(K.dptr(ac.q), K.dptr(legal8), n, ac.n_actions, 0.1, 1, 1, 0, K.dptr(acts), s),
         }
         flops = {"hb_actor_hidden": 2.0 * ac.k_pad * ac.hidden * n, "hb_actor_q": 2.0 * ac.hidden * ac.w2t.shape[0] * n}
+        if ac.takes_fused(obs8):
+            # round 3: the whole forward + selection as ONE kernel (csrc/actor_fused.hip): what the loop runs
+            f = ac._fset_ptrs[0]
+            n_pass = (ac.n_actions + 9) // 10
+            launches = dict({"hb_actor_fused_act": lambda: L.hb_actor_fused_act(
+                K.dptr(obs8), K.dptr(legal8), n, ac.obs_len, f[0], f[1], f[2], f[3], K.dptr(support), ac.hidden, ac.n_actions, ac.n_atoms,
+                K.dptr(ac.q), 0.1, 1, 1, 0, K.dptr(acts), s)}, **launches)
+            flops["hb_actor_fused_act"] = 2.0 * n * (ac.k_pad * ac.hidden + ac.hidden * 512 * n_pass)
         per_kernel = {}
         for name, fn in launches.items():
             for _ in range(3):
@@ -702,7 +761,10 @@ def qnet_roofline(agent, env, args):
             "actor_forward": {"rows": n, "executed_gflop": exec_flop * n / 1e9, "ms": actor_s * 1e3, "achieved": exec_tf,
                               "frac": exec_tf / peak, "algorithmic_gflop": fwd_flop * n / 1e9, "algorithmic_achieved": actor_tf,
                               "algorithmic_frac": actor_tf / peak,
-                              "kernels": ("hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
+                              "kernels": ("hb_actor_fused_act: bit rows -> q values -> eps-greedy moves in ONE kernel (hand-written MFMA, "
+                                          "csrc/actor_fused.hip); per_kernel also times the two-kernel form it replaces"
+                                          if (mfma_actor and fl.actor.takes_fused(env.net_obs)) else
+                                          "hb_actor_hidden + hb_actor_q + hb_policy_select (hand-written MFMA, csrc/actor.hip)"
                                           if mfma_actor else "hb_actor_hidden (MFMA) + library GEMM [N,H]x[H,A] + hb_policy_select"
                                           if getattr(agent, "_plain_fast", False) else "hb_obs_cast + hipBLASLt GEMMs + hb_policy_act"),
                               "per_kernel": per_kernel},

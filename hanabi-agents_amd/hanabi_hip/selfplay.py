@@ -17,6 +17,8 @@ the driver itself moves no data. An agent's `obs_t` is its own next turn; when i
 between, step type is LAST and `obs_t` is already the first observation of the fresh game (which
 the learner ignores when `mask_terminal` is on).
 """
+import os
+
 import torch
 
 from . import _capi as K
@@ -83,6 +85,8 @@ class SelfPlaySession:
         # One host call per step (hb_chain_run, csrc/chain.hip): once a seat's step has run through the ordinary path below and
         # every buffer, event and the update's graph exist, the same launches are replayed from a command array filled once.
         self.native_chain = bool(native_chain) and env.device.type == "cuda"
+        self._acted_early = os.environ.get("HB_ACTED_BEFORE_ENV", "1") != "0"
+        self.select_in_env_steps = 0   # steps whose moves were picked inside the env kernel (hb_env_step_select_packed)
         self._chains = {}        # seat -> _Chain
         self.native_steps = 0
 
@@ -191,6 +195,20 @@ class SelfPlaySession:
             agent.add_experience(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
         else:
             agent.add_experience_dense(observations, self.last_actions[seat], env.agent_reward, env.agent_step_type)
+        early = self._acted_early and main is not None
+
+        def record_acted():
+            # The policy has read the weights: the learner may overwrite them from here on. Round 3: recorded BEFORE the env step,
+            # so the update's head (tree fill, sample + gather, forward GEMMs: small kernels that fit beside the others) starts
+            # while the env kernel runs: 0.124 -> 0.115 ms per step. (Rounds 1-2 recorded it after the env step: with the library
+            # GEMMs of the time the update's first kernels slowed the env kernel by as much as they gained.)
+            ev = self._acted_ev.get(seat)   # (re-recording an event does not disturb waits already enqueued on it)
+            if ev is None:
+                ev = self._acted_ev[seat] = K.Event()
+            ev.record(raw)
+            return ev
+
+        acted = None
         actions = None
         if self.fuse_select and hasattr(agent, "act_for_step"):
             # one-kernel actor: forward + selection in ONE launch; the env kernel then takes plain moves (4 B per game instead of
@@ -200,25 +218,23 @@ class SelfPlaySession:
         if actions is None and self.fuse_select and hasattr(agent, "q_for_step"):
             sel = agent.q_for_step(observations, explore)
         if actions is not None:
+            if early:
+                acted = record_acted()
             env.step(actions)
         elif sel is not None:
             # the network's q values go straight into the env kernel, which picks each game's move by the agent's own rule and
             # draws (identical actions) and applies it: no selection launch, no round trip of the actions
             actions = self._act_buf[seat]
             env.step_select(sel[0], sel[1], sel[2], sel[3], sel[4], actions_out=actions)
+            self.select_in_env_steps += 1
         else:
             actions = agent.explore(observations) if explore else agent.exploit(observations)
+            if early:
+                acted = record_acted()
             env.step(actions)
         self.last_actions[seat] = actions
-        acted = None
-        if main is not None:
-            # The policy has read the weights: the learner may overwrite them from here on. Recorded AFTER the env step:
-            # releasing the learner before it is throughput-neutral (0.194 ms either way) but makes the HBM-bound env
-            # kernel share the chip with the update's first kernels (18 us per launch instead of 14).
-            acted = self._acted_ev.get(seat)   # (re-recording an event does not disturb waits already enqueued on it)
-            if acted is None:
-                acted = self._acted_ev[seat] = K.Event()
-            acted.record(raw)
+        if main is not None and acted is None:
+            acted = record_acted()
         self.env_steps += env.n
         if self.learner_stream is None:
             self._train_inline(agent, seat, train)
@@ -411,10 +427,14 @@ class _Chain:
              session._act_buf[seat].data_ptr()],
             [env.n, act.obs_len, act.hidden, act.n_actions, act.n_atoms, agent.params.seed + 0x9E3779B9, agent.first_game_id],
             var=1, fvar=0)
-        put(4, K.CMD_ENV_STEP_PACKED, A,
+        # `acted` (the policy has read its weights: this agent's update may start) is recorded BEFORE the env step here: the
+        # update's head (tree fill, sample + gather) then runs beside the env kernel. (The ordinary path records it after the
+        # env step, a round-1 measurement with the library GEMMs; either order gives the same results.)
+        early = session._acted_early
+        put(5 if early else 4, K.CMD_ENV_STEP_PACKED, A,
             [env.h, session._act_buf[seat].data_ptr(), env.obs_bits.data_ptr(), None, env.legal.data_ptr(), env.reward.data_ptr(),
              env.terminal.data_ptr(), env.agent_reward.data_ptr(), env.agent_step_type.data_ptr(), env.score.data_ptr()])
-        put(5, K.CMD_RECORD_EVENT, A, [acted.h])
+        put(4 if early else 5, K.CMD_RECORD_EVENT, A, [acted.h])
         put(6, K.CMD_WAIT_EVENT, Ls, [acted.h])
         put(7, K.CMD_TREE_FILL_RANGE, Ls, [buf.sum_tree.h, buf._max_priority.data_ptr()], var=2)
         g = fl._sg_call[3]              # hb_per_sample_gather's arguments in declaration order
