@@ -82,6 +82,15 @@ int hb_chain_run(const hb_cmd* cmds, int32_t count, const int64_t* vars_i, const
         rc = hb_per_update(static_cast<hb_tree*>(c.p[0]), static_cast<const int64_t*>(c.p[1]), static_cast<const float*>(c.p[2]), c.i[0],
                            c.f[0], static_cast<float*>(c.p[3]), static_cast<float*>(c.p[4]), c.stream);
         break;
+      case HB_CMD_ACTOR_FUSED_PACK:
+        rc = hb_actor_fused_pack(c.p[0], static_cast<int32_t>(c.i[0]), c.p[1], c.p[2], static_cast<int32_t>(c.i[1]), c.p[3],
+                                 static_cast<int32_t>(c.i[2]), static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]),
+                                 static_cast<int32_t>(c.i[5]), c.p[4], static_cast<float*>(c.p[5]), c.p[6], static_cast<float*>(c.p[7]),
+                                 c.stream);
+        break;
+      case HB_CMD_ACTOR_PACK_WEIGHTS:   // p[0]: the caller's hb_pack_job array (host memory that outlives the chain), i[0]: count
+        rc = hb_actor_pack_weights(static_cast<const hb_pack_job*>(c.p[0]), static_cast<int32_t>(c.i[0]), c.stream);
+        break;
       default:
         return fail(HB_ERR_INVALID, "command %d: unknown op %d", k, c.op);
     }

@@ -347,12 +347,16 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   const long long gi = g0 + lane;
   int uid_in = 0;
   bool mask_in = true;
-  uint4 nd[4];  // this game's pre-shuffled next deck (64 B), in flight while the rules run; used only on a re-deal
+  // This game's pre-shuffled next deck (64 B), used only on a re-deal. Round 3: fetched only by games that CAN end with this
+  // move (one life left, deck empty, or one card short of a perfect score: ~1.5 % of the games re-deal in a step, rounds 1-2
+  // fetched the row for all of them: 2.1 MB of 14.8 MB per launch) — the request goes out as soon as the state row is in LDS
+  // and is in flight while the rules run; a masked reset knows at once.
+  uint4 nd[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  const uint4* const ndp = reinterpret_cast<const uint4*>(a.next_deck + gi * NEXT_DECK_BYTES);
   if (active) {
     if (mode == MODE_STEP) uid_in = a.sel_q ? select_action<K::A>(a, gi) : a.actions[gi];
     if (mode == MODE_RESET && a.mask) mask_in = a.mask[gi] != 0;
-    if (mode != MODE_OBSERVE) {
-      const uint4* ndp = reinterpret_cast<const uint4*>(a.next_deck + gi * NEXT_DECK_BYTES);
+    if (mode == MODE_RESET && mask_in) {
       nd[0] = ndp[0]; nd[1] = ndp[1]; nd[2] = ndp[2]; nd[3] = ndp[3];
     }
   }
@@ -412,6 +416,14 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
       keep_seats = false;
       reset_start = a.start_player;
     } else if (mode == MODE_STEP && ((w0 >> 19) & 3) == 0) {
+      {   // can this move end the game? (lives run out / the last firework card / the last turn after the deck ran dry)
+        int fsum = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) fsum += fw(c);
+        if (((w0 >> 10) & 7) <= 1 || (w0 & 63) == 0 || fsum >= C * R - 1) {
+          nd[0] = ndp[0]; nd[1] = ndp[1]; nd[2] = ndp[2]; nd[3] = ndp[3];
+        }
+      }
       // The four move types are evaluated WITHOUT divergent branches: every effect is computed under a 0/1
       // predicate and selected in. (The branchy form spent ~60 % of this phase's instructions on exec-mask
       // bookkeeping and register copies at the joins.)

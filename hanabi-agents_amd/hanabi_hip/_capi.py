@@ -59,7 +59,7 @@ class HbCmd(C.Structure):
 
 
 (CMD_WAIT_EVENT, CMD_RECORD_EVENT, CMD_REPLAY_INSERT, CMD_ACTOR_FUSED_ACT, CMD_ENV_STEP_PACKED, CMD_TREE_FILL_RANGE,
- CMD_PER_SAMPLE_GATHER, CMD_GRAPH_LAUNCH, CMD_PER_UPDATE) = range(1, 10)
+ CMD_PER_SAMPLE_GATHER, CMD_GRAPH_LAUNCH, CMD_PER_UPDATE, CMD_ACTOR_FUSED_PACK, CMD_ACTOR_PACK_WEIGHTS) = range(1, 12)
 
 
 class HbRule(C.Structure):

@@ -99,9 +99,10 @@ class SelfPlaySession:
         if not (self.native_chain and train and self.learner_stream is not None and self.fuse_select and self.updates_per_step == 1
                 and seat in self.train_seats and self.t >= env.players and getattr(env, "packed", False)):
             return None
-        if not (hasattr(agent, "_fl") and getattr(agent, "split_update", False) and not getattr(agent, "actor_lag", 0)):
+        if not (hasattr(agent, "_fl") and getattr(agent, "split_update", False)):
             return None
         fl, p = agent._fl, agent.params
+        lag = int(getattr(agent, "actor_lag", 0))
         if (fl is None or fl.actor is None or fl.actor_stale or not p.use_priority or p.resample_noise or not agent.use_mfma_actor
                 or agent._graph1 is None or agent._graph2 is not None or agent._pending is not None or agent._pending_fills
                 or agent._dense_call is None or fl._sg_call is None or agent.gathered_ev is None or agent.weights_ev is None
@@ -110,9 +111,12 @@ class SelfPlaySession:
         if agent.train_step % p.target_update_period == 0:
             return None   # (this update is followed by a target sync: torch copies, ordinary path)
         buf = agent.experience
-        ch = self._chains.get(seat)
+        wset = fl.n_packed % 2 if lag else 0
+        if lag and (fl.packed_ev[wset] is None or fl.actor._two_stale[wset]):
+            return None   # (this weight set has not been through the ordinary path yet)
+        ch = self._chains.get((seat, wset))
         ls = self._learner_stream_of(agent)
-        key = (raw, ls.cuda_stream, agent._dense_call[0], fl._sg_call[0], fl._sg_call[1], id(agent._graph1), buf.rows_per_insert,
+        key = (raw, ls.cuda_stream, wset, agent._dense_call[0], fl._sg_call[0], fl._sg_call[1], id(agent._graph1), buf.rows_per_insert,
                self.last_actions[seat].data_ptr(), self._act_buf[seat].data_ptr(), agent._g_idx.data_ptr(), agent._g_prios.data_ptr())
         if ch is None or ch.key != key:
             # the cached insert call must be the one the ordinary path would make NOW (same seven operands, add_experience_dense)
@@ -120,7 +124,7 @@ class SelfPlaySession:
                    env.agent_step_type.data_ptr(), agent.last_obs.data_ptr(), buf._obs_t_buf.data_ptr())
             if agent._dense_call[0] != now or agent._dense_call[1] != env.n or self.last_actions[seat] is not self._act_buf[seat]:
                 return None
-            ch = self._chains[seat] = _Chain(self, seat, agent, raw, ls.cuda_stream, key)
+            ch = self._chains[(seat, wset)] = _Chain(self, seat, agent, raw, ls.cuda_stream, key, wset)
         return ch
 
     def _native_step(self, ch, seat, agent, explore):
@@ -131,7 +135,7 @@ class SelfPlaySession:
         agent._draws += 1
         vi[0], vi[1], vi[2], vi[3] = start, agent._draws, start, n
         vi[4] = 1 if (self._update_done.pop(id(agent), None) is not None and agent.gathered_ev.recorded) else 0
-        vi[5] = 1 if agent.weights_ev.recorded else 0
+        vi[5] = 1 if ((fl.packed_ev[ch.wset].recorded if ch.lag else agent.weights_ev.recorded)) else 0
         vf[0] = float(agent.params.epsilon(agent.train_step)) if explore else 0.0
         buf._advance(n)
         # device scalars the update reads: refreshed (on the learner stream, as update_begin does) only when they change
@@ -148,10 +152,14 @@ class SelfPlaySession:
         K.check(ch.run(ch.cmds, ch.count, vi, vf))
         agent.gathered_ev.recorded = agent.weights_ev.recorded = True
         self._acted_ev[seat].recorded = True
+        if ch.lag:   # (weights_updated() of the ordinary path: the set just packed, and its event)
+            fl.packed_ev[ch.wset].recorded = True
+            fl.n_packed += 1
         env._obs_stale = True
         self.last_actions[seat] = self._act_buf[seat]
         agent._eff_cache = None
-        fl.weights_updated()
+        if not ch.lag:
+            fl.weights_updated()
         agent.train_step += 1
         self._update_done[id(agent)] = ch.done
         self.env_steps += n
@@ -391,12 +399,13 @@ class _Chain:
     leaves of the inserted rows, sample + gather, record `gathered`, the captured update, record `weights`, priority write-back.
     The same launches in the same order on the same streams as SelfPlaySession.step's ordinary path."""
 
-    def __init__(self, session, seat, agent, raw, lraw, key):
+    def __init__(self, session, seat, agent, raw, lraw, key, wset=0):
         import ctypes as C
 
         env, buf, fl = session.env, agent.experience, agent._fl
         self.key, self.ls = key, session._learner_stream_of(agent)
-        cmds = (K.HbCmd * 13)()
+        self.wset, self.lag = wset, bool(getattr(agent, "actor_lag", 0))
+        cmds = (K.HbCmd * 16)()
         A, Ls = C.c_void_p(raw), C.c_void_p(lraw)
 
         def put(k, op, stream, ptrs=(), ints=(), floats=(), var=-1, fvar=-1, cond=-1):
@@ -417,9 +426,11 @@ class _Chain:
         ins = agent._dense_call[3]      # hb_replay_insert's fixed arguments: 12 pointers, n, row bytes, n_actions, capacity
         put(0, K.CMD_WAIT_EVENT, A, [agent.gathered_ev.h], cond=4)
         put(1, K.CMD_REPLAY_INSERT, A, ins[:12], ins[12:16], var=0)
-        put(2, K.CMD_WAIT_EVENT, A, [agent.weights_ev.h], cond=5)
+        # synchronous agent: the policy waits for the weights of this agent's last update; actor_lag = 1: for the launch that packed
+        # the weight set it reads (update before last: long past)
+        put(2, K.CMD_WAIT_EVENT, A, [(fl.packed_ev[wset] if self.lag else agent.weights_ev).h], cond=5)
         act = fl.actor
-        f = act._fset_ptrs[0]
+        f = act._fset_ptrs[wset]
         if agent._support0 is None:
             agent._support0 = agent.atoms[0].contiguous()
         put(3, K.CMD_ACTOR_FUSED_ACT, A,
@@ -443,13 +454,25 @@ class _Chain:
             [g[1], g[3], g[11], g[12], g[14], g[15], g[20], g[22], g[23]], [g[21]])
         put(9, K.CMD_RECORD_EVENT, Ls, [agent.gathered_ev.h])
         put(10, K.CMD_GRAPH_LAUNCH, Ls, [agent._graph1.raw_cuda_graph_exec()])
-        put(11, K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
+        k = 11
+        if self.lag:
+            # FusedLearner.weights_updated(): the update's result goes into the weight set the NEXT-but-one policy call reads
+            # (both forms of the copies), followed by that set's event
+            (w1, b1), (w2, b2) = fl.eff
+            put(k, K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]],
+                [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms])
+            jobs = next(j for kk, j in act._jobs.items() if kk[0] == wset and kk[1] == w1.data_ptr())
+            self._jobs = jobs   # (kept alive: the command holds its address)
+            put(k + 1, K.CMD_ACTOR_PACK_WEIGHTS, Ls, [C.addressof(jobs)], [2])
+            put(k + 2, K.CMD_RECORD_EVENT, Ls, [fl.packed_ev[wset].h])
+            k += 3
+        put(k, K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
         prios = agent._g_prios
         assert prios.dtype == torch.float32 and prios.is_contiguous() and agent._g_idx.dtype == torch.int64
-        put(12, K.CMD_PER_UPDATE, Ls,
+        put(k + 1, K.CMD_PER_UPDATE, Ls,
             [buf.sum_tree.h, agent._g_idx.data_ptr(), prios.data_ptr(), buf._max_priority.data_ptr(), buf._min_priority.data_ptr()],
             [agent._g_idx.numel()], [buf.alpha])
-        self.cmds, self.count = cmds, 13
+        self.cmds, self.count = cmds, k + 2
         self.vi = (C.c_int64 * 8)()
         self.vf = (C.c_double * 2)()
         self.run = K.lib().hb_chain_run

@@ -133,7 +133,7 @@ def test_fused_learner_reduced_precision_vs_fp32_autograd(dtype, players):
     measured["samples_with_clear_selection"] = float(clear.float().mean())
     measured["td_rel_l2"] = _rel_l2(td_lp, td32)
     _record(f"learner_{dtype}_{players}p", {"measured": measured, "tolerance": tol})
-    assert measured["samples_with_clear_selection"] > 0.3, measured
+    assert measured["samples_with_clear_selection"] > 0.8, measured
     assert bool((err_td <= bound)[clear].all()), measured
     assert measured["loss_rel_err"] <= tol["loss_rel"], measured
     assert measured["is_weight_max_abs_err"] <= tol["is_weight_abs"], measured
@@ -209,6 +209,6 @@ def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, form, players):
                 "median_top2_gap": float(gap.median())}
     _record(f"actor_{dtype}_{form}_{players}p", {"measured": measured, "tolerance": {k: tol[k] for k in ("q_abs", "argmax_gap")}})
     assert measured["q_max_abs_err"] <= tol["q_abs"], measured
-    assert measured["rows_with_clear_gap"] > 0.3, measured
+    assert measured["rows_with_clear_gap"] > (0.55 if dtype == "bfloat16" else 0.85), measured
     assert bool(agree[clear].all()), measured
     assert bool(legal.gather(1, act.long()[:, None]).all())

@@ -209,8 +209,7 @@ def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
     fl = agents[0]._fl
     assert fl.actor is not None and fl.actor.fused and all(a.split_update for a in agents) and sess._stream_per_agent
     assert agents[0]._graph1 is not None and sess.grad_steps >= steps - 4
-    if lag == 0:
-        assert sess.native_steps >= steps - 10, sess.native_steps     # most steps went through hb_chain_run
+    assert sess.native_steps >= steps - 12, sess.native_steps     # most steps went through hb_chain_run
     assert env.illegal_count() == 0
     for seat in (0, 1):
         buf = agents[seat].experience
@@ -224,7 +223,8 @@ def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
             assert np.array_equal(tr.legal_moves_t[sl], lg) and np.array_equal(tr.terminal_t[sl, 0], term)
 
 
-def test_one_host_call_per_step_gives_identical_training(monkeypatch):
+@pytest.mark.parametrize("lag", [0, 1])
+def test_one_host_call_per_step_gives_identical_training(lag, monkeypatch):
     """SelfPlaySession(native_chain=True): the step replayed from an hb_cmd array by ONE hb_chain_run call (csrc/chain.hip) against
     the ordinary path's ~25 host calls: same moves every step, identical weights, moments, replay rings, sum trees and env rows."""
     import torch
@@ -240,7 +240,8 @@ def test_one_host_call_per_step_gives_identical_training(monkeypatch):
         flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
         env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=1024, seed=5, packed=True)
         params = RlaxRainbowParams(train_batch_size=128, experience_buffer_size=1024 * 8, mask_terminal=True, target_update_period=6,
-                                   compute_dtype="bfloat16", packed_obs=True, layers=[512], learning_rate=0.01, n_step=n_step)
+                                   compute_dtype="bfloat16", packed_obs=True, layers=[512], learning_rate=0.01, n_step=n_step,
+                                   actor_lag=lag)
         agents = [DQNAgent(ObservationSpec((1024, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
                   for s in (1, 2)]
         sess = SelfPlaySession(env, agents, native_chain=native)
@@ -250,7 +251,7 @@ def test_one_host_call_per_step_gives_identical_training(monkeypatch):
             acts.append(sess.last_actions[(sess.t - 1) % 2].clone())
         sess.flush()
         torch.cuda.synchronize()
-        assert (sess.native_steps > 20) == native, sess.native_steps
+        assert (sess.native_steps > 18) == native, sess.native_steps
         out = [env.export_state(), env.obs_bits.clone()]
         for a in agents:
             out += [torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]), a.experience.sum_tree.nodes(),
