@@ -303,6 +303,11 @@ def main():
         return launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    # stdout carries exactly ONE line, the JSON result. Libraries write there too (RCCL prints its version banner to fd 1 when the
+    # first communicator is created): from here on fd 1 is stderr, and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     # rehearsal knobs (one-GPU box): HB_BENCH_DEVICE pins every rank to one device, HB_DIST_BACKEND=gloo replaces RCCL,
     # which needs one GPU per rank. The driver sets neither.
     if "HB_BENCH_DEVICE" in os.environ:
@@ -595,7 +600,9 @@ def main():
     if force_coll:
         line["config"]["parallelism"] += " [HB_BENCH_FORCE_COLLECTIVE: one-rank RCCL group, multi-rank update path]"
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    os.close(result_fd)
     if world > 1:
         dist.barrier()
     if world > 1 or force_coll:

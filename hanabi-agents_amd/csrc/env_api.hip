@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -252,6 +253,10 @@ static int launch(hb_env* e, hb::EnvArgs& a, void* stream) {
   a.seed = e->seed;
   a.first_gid = e->first_gid;
   a.flags = e->cfg.flags;
+  {   // measurement aid: HB_ENV_DECK_ALWAYS=1 restores rounds 1-2's unconditional fetch of the deck-pool row
+    static const int always = [] { const char* v = getenv("HB_ENV_DECK_ALWAYS"); return v && v[0] == '1' ? 0x100 : 0; }();
+    a.flags |= always;
+  }
   a.ev_start = e->ev_start;
   a.ev_stop = e->ev_stop;
   // automatic: 32 games per wavefront when only the bit-packed rows leave the kernel and the batch is >= 32 768 games (one

@@ -327,6 +327,11 @@ __device__ __forceinline__ void wave_sync() {
 template <class K, int G>
 __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   constexpr int P = K::P, C = K::C, R = K::R, H = K::H;
+  // (Round 3 measured an encoder on all 64 lanes — 64 / G lanes per game, the knowledge slots and the other hands dealt out
+  //  over them and OR-ed into the bit row with ds_or_b32 — against this lane-per-game one: bit-identical and SLOWER, 10.5 vs
+  //  9.7 us at G = 16 and 10.8 vs 9.2 us at G = 32 (32 768 games): the LDS atomics and the two extra phases cost more than the
+  //  ~25 % of the encoder's instructions they save. DESIGN section 4.)
+  constexpr int LPG = 1;
   constexpr int PER_WAVE = G * (K::SWP + K::NWP + K::LW);
   __shared__ uint32_t lds[4 * PER_WAVE];
 
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
   if (active) {
     if (mode == MODE_STEP) uid_in = a.sel_q ? select_action<K::A>(a, gi) : a.actions[gi];
     if (mode == MODE_RESET && a.mask) mask_in = a.mask[gi] != 0;
-    if (mode == MODE_RESET && mask_in) {
+    if ((mode == MODE_RESET && mask_in) || (mode == MODE_STEP && (a.flags & 0x100))) {   // (0x100: measurement aid, fetch always)
       nd[0] = ndp[0]; nd[1] = ndp[1]; nd[2] = ndp[2]; nd[3] = ndp[3];
     }
   }
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
         int fsum = 0;
 #pragma unroll
         for (int c = 0; c < C; ++c) fsum += fw(c);
-        if (((w0 >> 10) & 7) <= 1 || (w0 & 63) == 0 || fsum >= C * R - 1) {
+        if (!(a.flags & 0x100) && (((w0 >> 10) & 7) <= 1 || (w0 & 63) == 0 || fsum >= C * R - 1)) {
           nd[0] = ndp[0]; nd[1] = ndp[1]; nd[2] = ndp[2]; nd[3] = ndp[3];
         }
       }
@@ -600,102 +605,105 @@ __global__ __launch_bounds__(256) void env_kernel(const EnvArgs a) {
     }
 
     if (mode != MODE_RESET) {
-      const int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7, o = (w0 >> 13) & 7;
-      BitAcc<K::NW> acc;
-      acc.clear();
-      uint64_t legal = 0;
-      const int n_o = hand_n(o);
-      // 1. other players' hands + "hand is short" flags; hint legality falls out of the same pass
-      static_for<P>([&](auto REL) {
-        constexpr int rel = decltype(REL)::value;
-        int p = o + rel;
-        if (p >= P) p -= P;
-        const int n_p = hand_n(p);
-        acc.template put<K::FLAGS_OFF + rel, 1>(n_p < H ? 1u : 0u);
-        if constexpr (rel >= 1) {
-          const uint32_t hc = row[K::W_HANDS + p];
-          uint32_t cmask = 0, rmask = 0;
+      const int o = (w0 >> 13) & 7;
+      if constexpr (LPG == 1) {
+        const int deck_size = w0 & 63, info = (w0 >> 6) & 15, life = (w0 >> 10) & 7;
+        BitAcc<K::NW> acc;
+        acc.clear();
+        uint64_t legal = 0;
+        const int n_o = hand_n(o);
+        // 1. other players' hands + "hand is short" flags; hint legality falls out of the same pass
+        static_for<P>([&](auto REL) {
+          constexpr int rel = decltype(REL)::value;
+          int p = o + rel;
+          if (p >= P) p -= P;
+          const int n_p = hand_n(p);
+          acc.template put<K::FLAGS_OFF + rel, 1>(n_p < H ? 1u : 0u);
+          if constexpr (rel >= 1) {
+            const uint32_t hc = row[K::W_HANDS + p];
+            uint32_t cmask = 0, rmask = 0;
+            static_for<H>([&](auto I) {
+              constexpr int i = decltype(I)::value;
+              const int card = (hc >> (5 * i)) & 31;
+              const bool have = i < n_p;
+              acc.template put<((rel - 1) * H + i) * K::BITS, K::BITS>(have ? (1u << card) : 0u);
+              if (have) { cmask |= 1u << (card / R); rmask |= 1u << (card % R); }
+            });
+            if (info > 0) {
+              legal |= static_cast<uint64_t>(cmask) << (2 * H + (rel - 1) * C);
+              legal |= static_cast<uint64_t>(rmask) << (2 * H + (P - 1) * C + (rel - 1) * R);
+            }
+          }
+        });
+        const uint32_t own = (1u << n_o) - 1u;
+        if (info < K::INFO) legal |= own;
+        legal |= static_cast<uint64_t>(own) << H;
+        // 2. board
+        acc.template put64<K::BOARD_OFF, K::DECK_T>((1ull << deck_size) - 1ull);
+        static_for<C>([&](auto CI) {
+          constexpr int c = decltype(CI)::value;
+          acc.template put<K::FW_OFF + c * R, R>((1u << fw(c)) >> 1);
+        });
+        acc.template put<K::INFO_OFF, K::INFO>((1u << info) - 1u);
+        acc.template put<K::LIFE_OFF, K::LIFE>((1u << life) - 1u);
+        // 3. discards: one thermometer per card identity,
+        acc.template put64<K::DISC_OFF, K::D>(disc);  // kept in this very form in the state row
+        // 4. most recent move, observer-relative
+        {
+          const uint32_t valid = w2 & 1u;
+          const int la_player = (w2 >> 1) & 7, la_type = (w2 >> 4) & 3, la_ci = (w2 >> 6) & 7, la_toff = (w2 >> 9) & 7;
+          const int la_color = (w2 >> 12) & 7, la_rank = (w2 >> 15) & 7;
+          const uint32_t la_scored = (w2 >> 18) & 1u, la_info = (w2 >> 19) & 1u, la_mask = (w2 >> 20) & 31u;
+          int actor = la_player - o;
+          if (actor < 0) actor += P;
+          int target = actor + la_toff;
+          if (target >= P) target -= P;
+          const uint32_t reveal = valid & static_cast<uint32_t>(la_type >= MV_RCOLOR);
+          const uint32_t cardmv = valid & static_cast<uint32_t>(la_type <= MV_DISCARD);
+          const uint32_t is_rc = valid & static_cast<uint32_t>(la_type == MV_RCOLOR);
+          const uint32_t is_rr = valid & static_cast<uint32_t>(la_type == MV_RRANK);
+          const uint32_t is_play = valid & static_cast<uint32_t>(la_type == MV_PLAY);
+          constexpr int o1 = K::LA_OFF, o2 = o1 + P, o3 = o2 + 4, o4 = o3 + P, o5 = o4 + C, o6 = o5 + R, o7 = o6 + H,
+                        o8 = o7 + H, o9 = o8 + K::BITS;
+          acc.template put<o1, P>(valid << actor);
+          acc.template put<o2, 4>(valid << la_type);
+          acc.template put<o3, P>(reveal << target);
+          acc.template put<o4, C>(is_rc << la_color);
+          acc.template put<o5, R>(is_rr << la_rank);
+          acc.template put<o6, H>(reveal ? la_mask : 0u);
+          acc.template put<o7, H>(cardmv << la_ci);
+          acc.template put<o8, K::BITS>(cardmv << (la_color * R + la_rank));
+          acc.template put<o9, 2>((is_play & la_scored) | ((is_play & la_info) << 1));
+        }
+        // 5. card knowledge, observer first
+        static_for<P>([&](auto REL) {
+          constexpr int rel = decltype(REL)::value;
+          int p = o + rel;
+          if (p >= P) p -= P;
+          const int n_p = hand_n(p);
+          const uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * p + 1]) << 32) | row[K::W_KNOW + 2 * p];
           static_for<H>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            const int card = (hc >> (5 * i)) & 31;
-            const bool have = i < n_p;
-            acc.template put<((rel - 1) * H + i) * K::BITS, K::BITS>(have ? (1u << card) : 0u);
-            if (have) { cmask |= 1u << (card / R); rmask |= 1u << (card % R); }
+            const uint32_t k = static_cast<uint32_t>(kn >> (12 * i)) & 0xFFFu;
+            const uint32_t cp = k & 31u, rp = (k >> 5) & 31u;
+            const uint32_t plaus = __umul24(spread_colors<C, R>(cp), rp);  // disjoint R-bit fields: no carries
+            const uint32_t ch = (k >> 10) & 1u, rh = (k >> 11) & 1u;
+            uint64_t v = plaus | (static_cast<uint64_t>(ch ? cp : 0u) << K::BITS) |
+                         (static_cast<uint64_t>(rh ? rp : 0u) << (K::BITS + C));
+            if (i >= n_p) v = 0;
+            acc.template put64<K::KN_OFF + (rel * H + i) * K::KN_SLOT, K::KN_SLOT>(v);
           });
-          if (info > 0) {
-            legal |= static_cast<uint64_t>(cmask) << (2 * H + (rel - 1) * C);
-            legal |= static_cast<uint64_t>(rmask) << (2 * H + (P - 1) * C + (rel - 1) * R);
-          }
-        }
-      });
-      const uint32_t own = (1u << n_o) - 1u;
-      if (info < K::INFO) legal |= own;
-      legal |= static_cast<uint64_t>(own) << H;
-      // 2. board
-      acc.template put64<K::BOARD_OFF, K::DECK_T>((1ull << deck_size) - 1ull);
-      static_for<C>([&](auto CI) {
-        constexpr int c = decltype(CI)::value;
-        acc.template put<K::FW_OFF + c * R, R>((1u << fw(c)) >> 1);
-      });
-      acc.template put<K::INFO_OFF, K::INFO>((1u << info) - 1u);
-      acc.template put<K::LIFE_OFF, K::LIFE>((1u << life) - 1u);
-      // 3. discards: one thermometer per card identity,
-      acc.template put64<K::DISC_OFF, K::D>(disc);  // kept in this very form in the state row
-      // 4. most recent move, observer-relative
-      {
-        const uint32_t valid = w2 & 1u;
-        const int la_player = (w2 >> 1) & 7, la_type = (w2 >> 4) & 3, la_ci = (w2 >> 6) & 7, la_toff = (w2 >> 9) & 7;
-        const int la_color = (w2 >> 12) & 7, la_rank = (w2 >> 15) & 7;
-        const uint32_t la_scored = (w2 >> 18) & 1u, la_info = (w2 >> 19) & 1u, la_mask = (w2 >> 20) & 31u;
-        int actor = la_player - o;
-        if (actor < 0) actor += P;
-        int target = actor + la_toff;
-        if (target >= P) target -= P;
-        const uint32_t reveal = valid & static_cast<uint32_t>(la_type >= MV_RCOLOR);
-        const uint32_t cardmv = valid & static_cast<uint32_t>(la_type <= MV_DISCARD);
-        const uint32_t is_rc = valid & static_cast<uint32_t>(la_type == MV_RCOLOR);
-        const uint32_t is_rr = valid & static_cast<uint32_t>(la_type == MV_RRANK);
-        const uint32_t is_play = valid & static_cast<uint32_t>(la_type == MV_PLAY);
-        constexpr int o1 = K::LA_OFF, o2 = o1 + P, o3 = o2 + 4, o4 = o3 + P, o5 = o4 + C, o6 = o5 + R, o7 = o6 + H,
-                      o8 = o7 + H, o9 = o8 + K::BITS;
-        acc.template put<o1, P>(valid << actor);
-        acc.template put<o2, 4>(valid << la_type);
-        acc.template put<o3, P>(reveal << target);
-        acc.template put<o4, C>(is_rc << la_color);
-        acc.template put<o5, R>(is_rr << la_rank);
-        acc.template put<o6, H>(reveal ? la_mask : 0u);
-        acc.template put<o7, H>(cardmv << la_ci);
-        acc.template put<o8, K::BITS>(cardmv << (la_color * R + la_rank));
-        acc.template put<o9, 2>((is_play & la_scored) | ((is_play & la_info) << 1));
-      }
-      // 5. card knowledge, observer first
-      static_for<P>([&](auto REL) {
-        constexpr int rel = decltype(REL)::value;
-        int p = o + rel;
-        if (p >= P) p -= P;
-        const int n_p = hand_n(p);
-        const uint64_t kn = (static_cast<uint64_t>(row[K::W_KNOW + 2 * p + 1]) << 32) | row[K::W_KNOW + 2 * p];
-        static_for<H>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          const uint32_t k = static_cast<uint32_t>(kn >> (12 * i)) & 0xFFFu;
-          const uint32_t cp = k & 31u, rp = (k >> 5) & 31u;
-          const uint32_t plaus = __umul24(spread_colors<C, R>(cp), rp);  // disjoint R-bit fields: no carries
-          const uint32_t ch = (k >> 10) & 1u, rh = (k >> 11) & 1u;
-          uint64_t v = plaus | (static_cast<uint64_t>(ch ? cp : 0u) << K::BITS) |
-                       (static_cast<uint64_t>(rh ? rp : 0u) << (K::BITS + C));
-          if (i >= n_p) v = 0;
-          acc.template put64<K::KN_OFF + (rel * H + i) * K::KN_SLOT, K::KN_SLOT>(v);
         });
-      });
-      uint32_t* ob = obits + lane * K::NWP;
-#pragma unroll
-      for (int i = 0; i < K::NW; ++i) ob[i] = acc.w[i];
-#pragma unroll
-      for (int i = K::NW; i < K::NWP; ++i) ob[i] = 0;
-      uint32_t* lb = lbits + lane * K::LW;
-      lb[0] = static_cast<uint32_t>(legal);
-      lb[1] = static_cast<uint32_t>(legal >> 32);
-      lb[2] = 0;
+        uint32_t* ob = obits + lane * K::NWP;
+  #pragma unroll
+        for (int i = 0; i < K::NW; ++i) ob[i] = acc.w[i];
+  #pragma unroll
+        for (int i = K::NW; i < K::NWP; ++i) ob[i] = 0;
+        uint32_t* lb = lbits + lane * K::LW;
+        lb[0] = static_cast<uint32_t>(legal);
+        lb[1] = static_cast<uint32_t>(legal >> 32);
+        lb[2] = 0;
+      }
       // per-game scalars (coalesced: consecutive lanes, consecutive addresses)
       const uint32_t pend = (w3 >> o) & 1u, tsin = (w3 >> (5 + o)) & 1u;
       if (a.agent_reward) a.agent_reward[gi] = pend ? static_cast<float>(static_cast<int8_t>(accw >> (8 * o))) : 0.f;
