@@ -16,7 +16,7 @@ python3 bench.py > $O/full_bench.json 2> $O/full_bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_settings.json 2>> $O/err.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -- python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant > $O/full_bench_under_rocprof.json 2>> $O/err.log
 cp $(ls $O/prof_full/*/*kernel_stats.csv | head -1) $O/full_kernel_stats.csv
-python3 scripts/timeline.py $O/prof_full > $O/timeline_sync.txt
+python3 scripts/timeline.py $O/prof_full 100 250 > $O/timeline_sync.txt
 rm -rf $O/prof_full
 python3 bench.py --env-only --steps 300 --warmup 50 --no-cpu-baseline > $O/env_only_bench.json 2>> $O/err.log
 python3 bench.py --env-only --unpacked-obs --steps 300 --warmup 50 --no-cpu-baseline > $O/env_only_int8_bench.json 2>> $O/err.log
@@ -40,8 +40,8 @@ python3 bench.py > $O/full_bench.json 2> $O/full_bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_settings.json 2>> $O/err.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_full -- python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant > $O/full_bench_under_rocprof.json 2>> $O/err.log
 cp $(ls $O/prof_full/*/*kernel_stats.csv | head -1) $O/full_kernel_stats.csv
-python3 scripts/timeline.py $O/prof_full > $O/timeline_sync.txt
-python3 scripts/timeline_gantt.py $O/prof_full 200 4 > $O/gantt_sync.txt
+python3 scripts/timeline.py $O/prof_full 100 250 > $O/timeline_sync.txt
+python3 scripts/timeline_gantt.py $O/prof_full 180 4 > $O/gantt_sync.txt
 rm -rf $O/prof_full
 # env kernel: packed step (the kernel form the loop runs), HBM traffic by PMC in separate passes
 python3 bench.py --env-only --steps 300 --warmup 50 --no-cpu-baseline > $O/env_only_bench.json 2>> $O/err.log
@@ -67,7 +67,7 @@ python3 bench.py --n-step 3 --no-cpu-baseline --no-async-variant > $O/bench_nste
 python3 bench.py --games 262144 --steps 60 --warmup 10 --no-cpu-baseline --no-async-variant --no-nstep-variant > $O/bench_262144_full_loop.json 2>> $O/err.log
 python3 bench.py --env-only --games 262144 --steps 100 --warmup 20 --no-cpu-baseline > $O/env_only_262144_bench.json 2>> $O/err.log
 rocprofv3 --kernel-trace --output-format csv -d $O/trace_async -- python3 bench.py --steps 300 --warmup 40 --no-cpu-baseline --actor-lag 1 --no-nstep-variant > /dev/null 2>> $O/err.log
-python3 scripts/timeline.py $O/trace_async > $O/timeline_async.txt
+python3 scripts/timeline.py $O/trace_async 100 250 > $O/timeline_async.txt
 rm -rf $O/trace_async
 ( for q in 2 3 4 8 16; do for coll in 0 1; do GPU_MAX_HW_QUEUES=$q HB_BENCH_FORCE_COLLECTIVE=$coll python3 bench.py --no-cpu-baseline --no-nstep-variant --steps 200 --warmup 40 2>/dev/null | python3 -c "
 import json,sys
