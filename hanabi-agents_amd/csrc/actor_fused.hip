@@ -47,7 +47,10 @@ constexpr int S2 = FH / 32;             // K steps of layer 2
 constexpr int LUT_BYTES = 65536;        // 256 byte values x 16 slots x 16 B
 constexpr int H_BYTES = FM * FH * 2;    // 131 072
 constexpr int FRAG_FLOATS = 3 * 8 * FM; // one buffer of quarter-action triples: [max | sum | weighted sum][wave][row] fp32 (12 KiB)
-constexpr int LDS_TOTAL = H_BYTES + 2 * FRAG_FLOATS * 4;   // 155 648: 8 KiB of the CU's 160 stay free for the learner's small kernels (tree fill, sample + gather, transposer), which run beside this kernel on another stream
+// 143 360 B = 112 of the CU's 128 LDS allocation granules (1 280 B): 20 KiB stay free for the learner's small kernels, which run beside
+// this kernel on another stream (tree fill: 8 KiB; sample + gather; transposer). With two triple buffers (155 648 B) the tree
+// fill's 8 192 B did NOT fit (7 680 B were left after rounding) and waited for this kernel to retire.
+constexpr int LDS_TOTAL = H_BYTES + FRAG_FLOATS * 4;
 constexpr float NEG_BIG = -1e30f;
 
 struct FusedArgs {
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     const f32x2 supZa = f32x2{sup_at(13 * fq + qd), sup_at(13 * fq + 4 + qd)};
     const f32x2 supZb = f32x2{sup_at(13 * fq + 8 + qd), sup_at(13 * fq + 12)};
     const bool full_ok = slot < A && slot < full_cap;
-    float* fb = reinterpret_cast<float*>(lds + H_BYTES) + (p & 1) * FRAG_FLOATS + wave * FM;   // component c: + c * 8 * FM
+    float* fb = reinterpret_cast<float*>(lds + H_BYTES) + wave * FM;   // component c: + c * 8 * FM
     // Written STAGE BY STAGE over the 8 row tiles (m is the inner loop everywhere): a wavefront issues in order, and one row
     // tile's softmax is a single dependent chain (max -> swaps -> exp -> sums -> swaps), so consecutive instructions must come
     // from different row tiles to keep the vector pipe busy (row tile after row tile: 9.6 k cycles per pass; see DESIGN).
@@ -454,14 +457,14 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
     });
     if (p < 2) HB_FSTAMP(8 + 3 * p);
     __syncthreads();
-    // ---- the pass's two extra actions: combine their four quarters (wavefronts 4 g .. 4 g + 3). The buffer alternates with the
-    // pass parity: the next pass's barrier separates these reads from the writes of pass p + 2.
+    // ---- the pass's two extra actions: combine their four quarters (wavefronts 4 g .. 4 g + 3). ONE buffer: a second barrier
+    // (below) separates these reads from the next pass's writes.
     if (tid < 2 * FM) {
       const int rr = tid & (FM - 1), g = tid >> 7;
       const int ea = full_cap + 2 * p + g;
       const long long row = row0 + rr;
       if (ea < A && row < a.m) {
-        const float* f = reinterpret_cast<const float*>(lds + H_BYTES) + (p & 1) * FRAG_FLOATS + (4 * g) * FM + rr;
+        const float* f = reinterpret_cast<const float*>(lds + H_BYTES) + (4 * g) * FM + rr;
         const float m0 = f[0], m1 = f[FM], m2 = f[2 * FM], m3 = f[3 * FM];
         const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         const float e0 = exp2_fast(m0 - M), e1 = exp2_fast(m1 - M), e2 = exp2_fast(m2 - M), e3 = exp2_fast(m3 - M);
@@ -472,6 +475,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
         a.q[row * A + ea] = T * __builtin_amdgcn_rcpf(S) * (1.0f / FK);
       }
     }
+    if (p + 1 < n_pass) __syncthreads();
     if (p < 2) HB_FSTAMP(9 + 3 * p);
   }
   if (a.legal) {

@@ -216,6 +216,7 @@ class DQNAgent:
         # `gathered_ev`, and the priority write-back runs after `weights_ev` — so the acting stream may insert as soon as the
         # rings have been read and act as soon as Adam has written the weights, instead of waiting for the whole update
         self.split_update = bool(self.actor_lag)
+        self.two_graphs = False   # set_two_graphs()
         self._pending_fills = []    # (start, rows) of inserts whose sum-tree leaves the NEXT update_begin() sets
         self.gathered_ev = None     # recorded when an update has finished reading the replay rings
         self.weights_ev = None      # recorded when an update's optimizer step is done (before its priority write-back)
@@ -543,6 +544,18 @@ class DQNAgent:
     # replay insert, policy and env step between the two calls, so the ~3.4 MB gradient exchange over xGMI hides
     # behind ~0.2 ms of independent work. With one rank the pair is exactly update() — and, under HIP graphs, the whole
     # update (Adam included) is one graph launched by update_begin(): do not let anything read the weights between the two.
+    def set_two_graphs(self, on=True):
+        """Capture the update as TWO graphs — everything that only READS the weights (forward, loss, backward), then the optimizer
+        step with the weight packs — although no collective sits between them: a driver can then start the first half BEFORE this
+        agent's policy call has finished (both only read the weights) and hold just the second half back (SelfPlaySession's
+        early update, hb_chain_run). Synchronous split-update agents only; results do not depend on it."""
+        on = bool(on)
+        if on != self.two_graphs:
+            assert self._pending is None
+            self.two_graphs = on
+            self._graph1 = self._graph2 = None
+        return on
+
     def set_split_update(self, on=True):
         """Turn the split form of update() on (see __init__) for a synchronous agent; returns whether it is in effect. Needs
         the fused learner with prioritized replay; agents with actor_lag always use it. Results do not depend on it."""
@@ -888,7 +901,7 @@ class DQNAgent:
         self._graph1, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: calls made by OTHER threads while we capture (the RCCL watchdog polling its events in a
         # data-parallel run) must not invalidate the capture
-        if not self._collective():
+        if not self._collective() and not (self.two_graphs and not self.actor_lag and self.split_update):
             # no collective between the halves: one graph, one launch (graph2 stays empty-handed: see update_finish)
             with torch.cuda.graph(self._graph1, capture_error_mode="thread_local"):
                 self.last_loss, self._g_idx, self._g_prios = self._update_part1()

@@ -27,7 +27,7 @@ from . import _capi as K
 class SelfPlaySession:
     def __init__(self, env, agents, updates_per_step=1, min_replay=None, train_seats=None, overlap_allreduce=None,
                  learner_stream=True, learner_priority=-1, stream_per_agent=None, fuse_select=True, split_update=True,
-                 native_chain=True):
+                 native_chain=True, early_update=True):
         assert len(agents) == env.players, "one agent per seat"
         self.env = env
         self.agents = list(agents)
@@ -85,6 +85,18 @@ class SelfPlaySession:
         # One host call per step (hb_chain_run, csrc/chain.hip): once a seat's step has run through the ordinary path below and
         # every buffer, event and the update's graph exist, the same launches are replayed from a command array filled once.
         self.native_chain = bool(native_chain) and env.device.type == "cuda"
+        # Early update (round 3, with the one-call step): an agent's update starts right after its replay INSERT — beside its own
+        # policy kernel, which like the update's forward / loss / backward only reads the weights — and only the optimizer step
+        # with the weight packs waits for the policy kernel (`acted`). The reference's order of effects is unchanged (insert,
+        # act on W_t, update W_t -> W_t+1 from a ring that contains the inserted rows); what changes is that the update's head no
+        # longer sits between one policy kernel and the next (0.115 -> see DESIGN section 8).
+        self.early_update = (bool(early_update) and self.native_chain and self.learner_stream is not None
+                             and os.environ.get("HB_EARLY_UPDATE", "1") != "0")   # (the variable: A/B measurements)
+        if self.early_update:
+            for a in agents:
+                if hasattr(a, "set_two_graphs") and getattr(a, "split_update", False) and not getattr(a, "actor_lag", 0):
+                    a.set_two_graphs(True)
+        self._inserted_ev = {}
         self._acted_early = os.environ.get("HB_ACTED_BEFORE_ENV", "1") != "0"
         self.select_in_env_steps = 0   # steps whose moves were picked inside the env kernel (hb_env_step_select_packed)
         self._chains = {}        # seat -> _Chain
@@ -104,7 +116,8 @@ class SelfPlaySession:
         fl, p = agent._fl, agent.params
         lag = int(getattr(agent, "actor_lag", 0))
         if (fl is None or fl.actor is None or fl.actor_stale or not p.use_priority or p.resample_noise or not agent.use_mfma_actor
-                or agent._graph1 is None or agent._graph2 is not None or agent._pending is not None or agent._pending_fills
+                or agent._graph1 is None or (agent._graph2 is not None) != bool(getattr(agent, "two_graphs", False) and not lag)
+                or agent._pending is not None or agent._pending_fills
                 or agent._dense_call is None or fl._sg_call is None or agent.gathered_ev is None or agent.weights_ev is None
                 or seat not in self._acted_ev or not self._ready(agent) or not fl.actor.takes_fused(env.net_obs)):
             return None
@@ -405,11 +418,13 @@ class _Chain:
         env, buf, fl = session.env, agent.experience, agent._fl
         self.key, self.ls = key, session._learner_stream_of(agent)
         self.wset, self.lag = wset, bool(getattr(agent, "actor_lag", 0))
-        cmds = (K.HbCmd * 16)()
+        cmds = (K.HbCmd * 20)()
         A, Ls = C.c_void_p(raw), C.c_void_p(lraw)
+        n_cmd = [0]
 
-        def put(k, op, stream, ptrs=(), ints=(), floats=(), var=-1, fvar=-1, cond=-1):
-            c = cmds[k]
+        def put(op, stream, ptrs=(), ints=(), floats=(), var=-1, fvar=-1, cond=-1):
+            c = cmds[n_cmd[0]]
+            n_cmd[0] += 1
             c.op, c.var, c.fvar, c.cond, c.stream = op, var, fvar, cond, stream
             for j, v in enumerate(ptrs):
                 c.p[j] = v.value if isinstance(v, C.c_void_p) else v
@@ -423,56 +438,69 @@ class _Chain:
         if done is None:
             done = session._done_ev[id(agent)] = K.Event()
         self.done = done
+        early = session.early_update and not self.lag   # (actor_lag = 1: measured no gain, 0.1147 vs 0.1132 ms per step)
         ins = agent._dense_call[3]      # hb_replay_insert's fixed arguments: 12 pointers, n, row bytes, n_actions, capacity
-        put(0, K.CMD_WAIT_EVENT, A, [agent.gathered_ev.h], cond=4)
-        put(1, K.CMD_REPLAY_INSERT, A, ins[:12], ins[12:16], var=0)
-        # synchronous agent: the policy waits for the weights of this agent's last update; actor_lag = 1: for the launch that packed
-        # the weight set it reads (update before last: long past)
-        put(2, K.CMD_WAIT_EVENT, A, [(fl.packed_ev[wset] if self.lag else agent.weights_ev).h], cond=5)
         act = fl.actor
         f = act._fset_ptrs[wset]
         if agent._support0 is None:
             agent._support0 = agent.atoms[0].contiguous()
-        put(3, K.CMD_ACTOR_FUSED_ACT, A,
+        # ---- acting stream
+        put(K.CMD_WAIT_EVENT, A, [agent.gathered_ev.h], cond=4)
+        put(K.CMD_REPLAY_INSERT, A, ins[:12], ins[12:16], var=0)
+        if early:
+            inserted = session._inserted_ev.get(seat)
+            if inserted is None:
+                inserted = session._inserted_ev[seat] = K.Event()
+            put(K.CMD_RECORD_EVENT, A, [inserted.h])
+        # synchronous agent: the policy waits for the weights of this agent's last update; actor_lag = 1: for the launch that packed
+        # the weight set it reads (update before last: long past)
+        put(K.CMD_WAIT_EVENT, A, [(fl.packed_ev[wset] if self.lag else agent.weights_ev).h], cond=5)
+        put(K.CMD_ACTOR_FUSED_ACT, A,
             [env.net_obs.data_ptr(), env.legal.data_ptr(), f[0], f[1], f[2], f[3], agent._support0.data_ptr(), act.q.data_ptr(),
              session._act_buf[seat].data_ptr()],
             [env.n, act.obs_len, act.hidden, act.n_actions, act.n_atoms, agent.params.seed + 0x9E3779B9, agent.first_game_id],
             var=1, fvar=0)
-        # `acted` (the policy has read its weights: this agent's update may start) is recorded BEFORE the env step here: the
-        # update's head (tree fill, sample + gather) then runs beside the env kernel. (The ordinary path records it after the
-        # env step, a round-1 measurement with the library GEMMs; either order gives the same results.)
-        early = session._acted_early
-        put(5 if early else 4, K.CMD_ENV_STEP_PACKED, A,
-            [env.h, session._act_buf[seat].data_ptr(), env.obs_bits.data_ptr(), None, env.legal.data_ptr(), env.reward.data_ptr(),
-             env.terminal.data_ptr(), env.agent_reward.data_ptr(), env.agent_step_type.data_ptr(), env.score.data_ptr()])
-        put(4 if early else 5, K.CMD_RECORD_EVENT, A, [acted.h])
-        put(6, K.CMD_WAIT_EVENT, Ls, [acted.h])
-        put(7, K.CMD_TREE_FILL_RANGE, Ls, [buf.sum_tree.h, buf._max_priority.data_ptr()], var=2)
+        # `acted` (the policy has read its weights) is recorded BEFORE the env step unless HB_ACTED_BEFORE_ENV=0
+        env_args = [env.h, session._act_buf[seat].data_ptr(), env.obs_bits.data_ptr(), None, env.legal.data_ptr(), env.reward.data_ptr(),
+                    env.terminal.data_ptr(), env.agent_reward.data_ptr(), env.agent_step_type.data_ptr(), env.score.data_ptr()]
+        if session._acted_early:
+            put(K.CMD_RECORD_EVENT, A, [acted.h])
+            put(K.CMD_ENV_STEP_PACKED, A, env_args)
+        else:
+            put(K.CMD_ENV_STEP_PACKED, A, env_args)
+            put(K.CMD_RECORD_EVENT, A, [acted.h])
+        # ---- learner stream. Early update: everything that only READS the weights starts as soon as the rows are in the ring —
+        # beside this agent's own policy kernel — and only what WRITES them (the optimizer step and the actor's weight copies;
+        # actor_lag: only the copies) waits for `acted`. Otherwise the whole update waits for `acted`.
+        put(K.CMD_WAIT_EVENT, Ls, [(inserted if early else acted).h])
+        put(K.CMD_TREE_FILL_RANGE, Ls, [buf.sum_tree.h, buf._max_priority.data_ptr()], var=2)
         g = fl._sg_call[3]              # hb_per_sample_gather's arguments in declaration order
-        put(8, K.CMD_PER_SAMPLE_GATHER, Ls,
+        put(K.CMD_PER_SAMPLE_GATHER, Ls,
             [g[0], g[2], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[13], g[16], g[17], g[18], g[19], g[24]],
             [g[1], g[3], g[11], g[12], g[14], g[15], g[20], g[22], g[23]], [g[21]])
-        put(9, K.CMD_RECORD_EVENT, Ls, [agent.gathered_ev.h])
-        put(10, K.CMD_GRAPH_LAUNCH, Ls, [agent._graph1.raw_cuda_graph_exec()])
-        k = 11
+        put(K.CMD_RECORD_EVENT, Ls, [agent.gathered_ev.h])
+        put(K.CMD_GRAPH_LAUNCH, Ls, [agent._graph1.raw_cuda_graph_exec()])
+        if early:
+            put(K.CMD_WAIT_EVENT, Ls, [acted.h])
+        if agent._graph2 is not None:
+            put(K.CMD_GRAPH_LAUNCH, Ls, [agent._graph2.raw_cuda_graph_exec()])
         if self.lag:
             # FusedLearner.weights_updated(): the update's result goes into the weight set the NEXT-but-one policy call reads
             # (both forms of the copies), followed by that set's event
             (w1, b1), (w2, b2) = fl.eff
-            put(k, K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]],
+            put(K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]],
                 [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms])
             jobs = next(j for kk, j in act._jobs.items() if kk[0] == wset and kk[1] == w1.data_ptr())
             self._jobs = jobs   # (kept alive: the command holds its address)
-            put(k + 1, K.CMD_ACTOR_PACK_WEIGHTS, Ls, [C.addressof(jobs)], [2])
-            put(k + 2, K.CMD_RECORD_EVENT, Ls, [fl.packed_ev[wset].h])
-            k += 3
-        put(k, K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
+            put(K.CMD_ACTOR_PACK_WEIGHTS, Ls, [C.addressof(jobs)], [2])
+            put(K.CMD_RECORD_EVENT, Ls, [fl.packed_ev[wset].h])
+        put(K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
         prios = agent._g_prios
         assert prios.dtype == torch.float32 and prios.is_contiguous() and agent._g_idx.dtype == torch.int64
-        put(k + 1, K.CMD_PER_UPDATE, Ls,
+        put(K.CMD_PER_UPDATE, Ls,
             [buf.sum_tree.h, agent._g_idx.data_ptr(), prios.data_ptr(), buf._max_priority.data_ptr(), buf._min_priority.data_ptr()],
             [agent._g_idx.numel()], [buf.alpha])
-        self.cmds, self.count = cmds, k + 2
+        self.cmds, self.count = cmds, n_cmd[0]
         self.vi = (C.c_int64 * 8)()
         self.vf = (C.c_double * 2)()
         self.run = K.lib().hb_chain_run
