@@ -245,7 +245,10 @@ def _rccl_worker(rank, world, port, out, lag):
         fl = agents[0]._fl
         assert fl.direct == (not force) and sess.grad_steps >= 26
         # two graphs: around the collective (force), or the early-update form of a synchronous split-update agent
-        assert (agents[0]._graph2 is not None) == (force is True or bool(getattr(agents[0], "two_graphs", False) and not agents[0].actor_lag))
+        # (force == "graph": the collective is captured INSIDE the one graph)
+        want2 = force is True or (force is False and bool(getattr(agents[0], "two_graphs", False) and not agents[0].actor_lag))
+        assert (agents[0]._graph2 is not None) == want2, (force, lag, agents[0]._graph2 is not None, agents[0].two_graphs,
+                                                          agents[0].split_update, sess.early_update)
         res[force] = dict(w=[torch.cat([p.detach().reshape(-1) for p in a.online.parameters()]).cpu() for a in agents],
                           loss=float(agents[0].last_loss), illegal=env.illegal_count())
     torch.save(res, os.path.join(out, "rccl.pt"))
