@@ -16,6 +16,7 @@
 //                    re-forms effective weights and the actor re-uses them
 // The GEMMs between them stay in hipBLASLt (torch.addmm / torch.mm on MFMA).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdint>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
@@ -320,72 +321,100 @@ struct AdamMulti {
   int count;
 };
 
-// four consecutive elements per thread (one 16-byte access per array); every tensor has cols % 4 == 0, n < 2^31 and
-// 16-byte aligned rows (checked on the host), so a group of four never straddles a row
-template <typename T>
-__device__ __forceinline__ void load_grad4(const void* g, int dtype, long long i, float out[4]) {
-  if (dtype == 0) {
-    const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(g) + i);
-    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-  } else if (dtype == 1) {
-    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __hip_bfloat16*>(g) + i);
-    out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xFFFF0000u);
-    out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xFFFF0000u);
-  } else {
-    const __half* h = static_cast<const __half*>(g) + i;
+// W consecutive elements per thread (one 16- or 8-byte access per array); every tensor has cols % 4 == 0, n < 2^31 and
+// 16-byte aligned rows (checked on the host), so a group never straddles a row
+// W consecutive elements per thread. W = 4 (16-byte accesses, 72 registers) is the form that runs; W = 2 (8-byte accesses,
+// 44 registers) fits into the 48 registers per SIMD lane the one-kernel actor (csrc/actor_fused.hip) leaves free and so runs
+// BESIDE the policy kernel instead of waiting for it — measured slower in the loop (hb_noisy_adam_multi below; DESIGN
+// section 5c "Co-residency"), kept for measurements. Same arithmetic per element in every form (adam1's explicit roundings).
+template <int W> struct VecW;
+template <> struct VecW<4> { typedef float4 type; };
+template <> struct VecW<2> { typedef float2 type; };
+// (element offsets are 32-bit unsigned — the host checks n < 2^30 — so every access is "scalar base + 32-bit lane offset": one
+//  address register per thread instead of a 64-bit pair per array)
+template <int W>
+__device__ __forceinline__ void ldw(const float* p, uint32_t off, float out[W]) {
+  const typename VecW<W>::type v = *reinterpret_cast<const typename VecW<W>::type*>(reinterpret_cast<const char*>(p) + static_cast<uint64_t>(off << 2));
+  const float* f = reinterpret_cast<const float*>(&v);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = __half2float(h[k]);
+  for (int k = 0; k < W; ++k) out[k] = f[k];
+}
+template <int W>
+__device__ __forceinline__ void stw(float* p, uint32_t off, const float in[W]) {
+  typename VecW<W>::type v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int k = 0; k < W; ++k) f[k] = in[k];
+  *reinterpret_cast<typename VecW<W>::type*>(reinterpret_cast<char*>(p) + static_cast<uint64_t>(off << 2)) = v;
+}
+template <int W>
+__device__ __forceinline__ void load_gradw(const void* g, int dtype, uint32_t i, float out[W]) {
+  if (dtype == 0) {
+    ldw<W>(static_cast<const float*>(g), i, out);
+  } else if (dtype == 1) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(static_cast<const char*>(g) + static_cast<uint64_t>(i << 1));
+    if constexpr (W == 4) {
+      const uint2 v = *reinterpret_cast<const uint2*>(p);
+      out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xFFFF0000u);
+      out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    } else {
+      const uint32_t v = *p;
+      out[0] = __uint_as_float(v << 16); out[1] = __uint_as_float(v & 0xFFFF0000u);
+    }
+  } else {
+    const __half* h = reinterpret_cast<const __half*>(static_cast<const char*>(g) + static_cast<uint64_t>(i << 1));
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[k] = __half2float(h[k]);
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void noisy_adam_multi4_kernel(const AdamMulti m) {
+template <typename T, int W>
+__global__ __launch_bounds__(256) void noisy_adam_multiw_kernel(const AdamMulti m) {
+  constexpr int SH = W == 4 ? 2 : 1;
   int ti = 0;
   while (ti + 1 < m.count && static_cast<int>(blockIdx.x) >= m.first[ti + 1]) ++ti;
   const AdamArgs& a = m.t[ti];
-  const int nb = m.first[ti + 1] - m.first[ti];
   const float t = *a.step + a.step_offset;
   const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
   T* eff = static_cast<T*>(a.eff);
-  const int n4 = static_cast<int>(a.n >> 2), c4 = a.cols >> 2;
-  for (int q = (static_cast<int>(blockIdx.x) - m.first[ti]) * 256 + static_cast<int>(threadIdx.x); q < n4; q += nb * 256) {
-    const int row = q / c4, col = (q - row * c4) << 2;
-    const long long i = static_cast<long long>(q) << 2;
-    float g[4];
-    load_grad4<T>(a.grad, a.grad_dtype, static_cast<long long>(row) * a.grad_ld + col, g);
-    const float4 nz4 = *reinterpret_cast<const float4*>(a.noise + i);
-    const float nz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
-    float res[3][4], lm[4], lv[4];
+  const int nw = static_cast<int>(a.n >> SH), cw = a.cols >> SH;
+  // (no grid-stride loop: the host launches one thread per group, so no address becomes a loop-carried 64-bit pointer)
+  const int q = (static_cast<int>(blockIdx.x) - m.first[ti]) * 256 + static_cast<int>(threadIdx.x);
+  if (q < nw) {
+    const int row = q / cw, col = (q - row * cw) << SH;
+    const uint32_t i = static_cast<uint32_t>(q) << SH;
+    float g[W], nz[W];
+    load_gradw<W>(a.grad, a.grad_dtype, static_cast<uint32_t>(row) * static_cast<uint32_t>(a.grad_ld) + col, g);
+    ldw<W>(a.noise, i, nz);
+    float res[3][W], lm[W], lv[W];
     auto one = [&](float* p, float* mp, float* vp, int which) {
-      float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(mp + i), vv = *reinterpret_cast<float4*>(vp + i);
-      float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+      float pa[W], ma[W], va[W];
+      ldw<W>(p, i, pa); ldw<W>(mp, i, ma); ldw<W>(vp, i, va);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < W; ++k) {
         pa[k] = adam1(pa[k], which == 2 ? __fmul_rn(g[k], nz[k]) : g[k], ma[k], va[k], a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
         res[which][k] = pa[k];
         lm[k] = ma[k];
         lv[k] = va[k];
       }
-      *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-      *reinterpret_cast<float4*>(mp + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
-      *reinterpret_cast<float4*>(vp + i) = make_float4(va[0], va[1], va[2], va[3]);
+      stw<W>(p, i, pa); stw<W>(mp, i, ma); stw<W>(vp, i, va);
     };
     one(a.w, a.m_w, a.v_w, 0);
+
     if (a.m_mu == a.m_w) {  // shared moments: apply w's step to w_mu
-      float4 pv = *reinterpret_cast<float4*>(a.w_mu + i);
-      pv.x = __fsub_rn(pv.x, adam_step(lm[0], lv[0], bc1, bc2s, a.lr, a.eps));
-      pv.y = __fsub_rn(pv.y, adam_step(lm[1], lv[1], bc1, bc2s, a.lr, a.eps));
-      pv.z = __fsub_rn(pv.z, adam_step(lm[2], lv[2], bc1, bc2s, a.lr, a.eps));
-      pv.w = __fsub_rn(pv.w, adam_step(lm[3], lv[3], bc1, bc2s, a.lr, a.eps));
-      *reinterpret_cast<float4*>(a.w_mu + i) = pv;
-      res[1][0] = pv.x; res[1][1] = pv.y; res[1][2] = pv.z; res[1][3] = pv.w;
+      float pv[W];
+      ldw<W>(a.w_mu, i, pv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) res[1][k] = pv[k] = __fsub_rn(pv[k], adam_step(lm[k], lv[k], bc1, bc2s, a.lr, a.eps));
+      stw<W>(a.w_mu, i, pv);
     } else {
       one(a.w_mu, a.m_mu, a.v_mu, 1);
     }
+
     one(a.w_sigma, a.m_sg, a.v_sg, 2);
-    const long long e = static_cast<long long>(row) * a.eff_ld + col;
+    const uint32_t e = static_cast<uint32_t>(row) * static_cast<uint32_t>(a.eff_ld) + col;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) st<T>(eff, e + k, merged(res[0][k], res[1][k], res[2][k], nz[k]));
+    for (int k = 0; k < W; ++k) st<T>(eff, e + k, merged(res[0][k], res[1][k], res[2][k], nz[k]));
   }
 }
 
@@ -572,12 +601,21 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
   AdamMulti m{};
   m.count = count;
   int blocks = 0;
-  bool vec4 = true;  // four elements per thread when every tensor allows 16-byte accesses
+  bool vec4 = true;  // several elements per thread when every tensor allows 16-byte accesses
+  // Elements per thread: 4 by default; HB_ADAM_WIDTH=2 is the 44-register form that fits beside the one-kernel actor, =1 the
+  // scalar one (36 registers). Same arithmetic per element in all three. Measured in the benched loop (round 3, same box,
+  // alternating): 4 -> 0.112-0.114 ms per step, 2 -> 0.120, 1 -> 0.117: an Adam that shares the CUs with the policy kernel
+  // streams its 55 MB through the L2 the policy kernel's weights live in and itself runs at one workgroup per CU; waiting for
+  // the CUs is faster. The narrow forms stay for measurements (profiles/r03/README.md).
+  const int width = [] { const char* e = getenv("HB_ADAM_WIDTH"); const int w = e ? atoi(e) : 4; return w == 2 || w == 1 ? w : 4; }();
+  if (width == 1) vec4 = false;
   for (int i = 0; i < count; ++i) {
     const hb_adam_tensor& d = tensors[i];
     const int gl = d.grad_ld ? d.grad_ld : d.cols;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    vec4 = vec4 && d.cols % 4 == 0 && d.n % 4 == 0 && d.n < (1LL << 31) && d.eff_ld % 4 == 0 && gl % 4 == 0 && al16(d.w) &&
+    // (32-bit element offsets inside the vector kernels: n < 2^30, rows * row stride < 2^31)
+    vec4 = vec4 && d.cols > 0 && d.cols % 4 == 0 && d.n % 4 == 0 && d.n < (1LL << 30) &&
+           (d.n / d.cols) * static_cast<long long>(d.eff_ld > gl ? d.eff_ld : gl) < (1LL << 31) && d.eff_ld % 4 == 0 && gl % 4 == 0 && al16(d.w) &&
            al16(d.w_mu) && al16(d.w_sigma) && al16(d.noise) && al16(d.grad) && al16(d.m_w) && al16(d.v_w) && al16(d.m_mu) &&
            al16(d.v_mu) && al16(d.m_sigma) && al16(d.v_sigma);
   }
@@ -592,15 +630,18 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
     m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
                       step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, d.grad_ld ? d.grad_ld : d.cols, lr, beta1, beta2, eps, step_offset};
     m.first[i] = blocks;
-    long long nb = ((vec4 ? d.n / 4 : d.n) + 255) / 256;
-    if (nb > 1024) nb = 1024;
+    long long nb = ((vec4 ? d.n / width : d.n) + 255) / 256;
+    if (!vec4 && nb > 1024) nb = 1024;   // (the vector kernels take one group per thread, the scalar one strides)
     blocks += static_cast<int>(nb);
   }
   m.first[count] = blocks;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec4 && eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi4_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
-  else if (vec4 && eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi4_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
-  else if (vec4 && eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi4_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
+  if (vec4 && width == 4 && eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multiw_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && width == 4 && eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multiw_kernel<__hip_bfloat16, 4>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && width == 4 && eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multiw_kernel<__half, 4>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multiw_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multiw_kernel<__hip_bfloat16, 2>), dim3(blocks), dim3(256), 0, s, m);
+  else if (vec4 && eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multiw_kernel<__half, 2>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 0) hipLaunchKernelGGL((noisy_adam_multi_kernel<float>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);

@@ -48,6 +48,9 @@ struct hb_tree {
   float* scratch;     // large per_update: transformed priorities
   long long scratch_n;
   bool single_wg;     // measurements only (env HB_TREE_UPDATE_PATH=single at creation): force update_small
+  bool fused_pow;     // the transform inside update_chunks (one launch, 72 registers); env HB_TREE_UPDATE_PATH=two at creation:
+                      // per_transform + update_chunks<false> (44 / 22 registers: both fit beside the one-kernel actor; same step time)
+  float* small_scratch;   // SMALL_MAX transformed priorities of a small hb_per_update
   bool lazy_top;      // hb_tree_set_lazy_top: writers leave the levels above the 1024-leaf subtrees stale, readers re-sum them
   bool top_stale;     // lazy mode was switched off: the stored top levels are made valid by the next reader or writer, on ITS stream
 };
@@ -168,13 +171,20 @@ __global__ __launch_bounds__(256) void chunk_kernel(float* __restrict__ nodes, l
 // running max / min priority and counts out-of-range indices. Result == update_small (every inner node is
 // fl(left + right) of its children either way).
 // ---------------------------------------------------------------------------------------------
+template <bool PER>   // PER: the priority transform (a double-precision pow) runs in here; false: `val` is written as it is
 __global__ __launch_bounds__(256) void update_chunks_kernel(float* __restrict__ nodes, long long cap, int chunk,
                                                             const int64_t* __restrict__ idx, const float* __restrict__ val,
-                                                            int n, int per_mode, double alpha, float* max_prio,
+                                                            int n, double alpha, float* max_prio,
                                                             float* min_prio, unsigned long long* errors) {
+  constexpr int per_mode = PER ? 1 : 0;
+  // 20 480 bytes of LDS in all (s, s_idx, s_chunk, s_stamp; the statistics workgroup's scratch aliases s): what the one-kernel
+  // actor leaves free on a CU (csrc/actor_fused.hip holds 143 360 B and 2 x 232 registers per SIMD lane: 20 480 B and 48
+  // registers are left). With the pow in here the kernel needs 72 registers; PER = false needs 22 and, behind per_transform_kernel
+  // (44), runs BESIDE the next policy kernel (HB_TREE_UPDATE_PATH=two). Measured in the benched loop: the same step time either
+  // way (0.112-0.114 ms), so the one-launch form stays the default (DESIGN section 5c "Co-residency").
   __shared__ float s[2048];
-  __shared__ __attribute__((aligned(16))) int s_idx[SMALL_MAX + 4];
-  __shared__ float s_red[2][4];
+  __shared__ __attribute__((aligned(16))) int s_idx[SMALL_MAX];
+  float (*s_red)[4] = reinterpret_cast<float (*)[4]>(s);
   const int tid = threadIdx.x;
   auto transformed = [&](float v) {
     // (priorities + 1e-10) ** alpha on float32 data (priority_buffer.py:49): float add, the power in double
@@ -215,12 +225,10 @@ __global__ __launch_bounds__(256) void update_chunks_kernel(float* __restrict__ 
   __shared__ int s_chunk[SMALL_MAX];
   __shared__ int s_stamp[1024];
   long long my_idx[4];
-  float my_val[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = tid + 256 * r;
     my_idx[r] = j < n ? idx[j] : -1;
-    my_val[r] = j < n ? val[j] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -232,8 +240,9 @@ __global__ __launch_bounds__(256) void update_chunks_kernel(float* __restrict__ 
     }
   }
   for (int j = tid; j < chunk; j += 256) s_stamp[j] = 0;
+  if (tid == 0) reinterpret_cast<volatile int*>(s)[0] = 0;
   __syncthreads();
-  const int my_chunk = s_chunk[blockIdx.x];
+  const int my_chunk = __builtin_amdgcn_readfirstlane(s_chunk[blockIdx.x]);   // workgroup-uniform: scalar registers
   if (my_chunk < 0) return;
   // do I own this subtree (no earlier entry falls into it)? and which entry wrote each of its leaves last?
   int earlier = 0;
@@ -249,16 +258,18 @@ __global__ __launch_bounds__(256) void update_chunks_kernel(float* __restrict__ 
   float keep[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) keep[r] = tid + 256 * r < chunk ? nodes[cap + leaf0 + tid + 256 * r] : 0.f;
-  if (__syncthreads_or(earlier)) return;
+  // (a flag in LDS instead of __syncthreads_or, which reserves LDS of its own; word 0 of s is never a tree node)
+  if (earlier) reinterpret_cast<volatile int*>(s)[0] = 1;
+  __syncthreads();
+  if (reinterpret_cast<volatile int*>(s)[0]) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (tid + 256 * r < chunk) s[chunk + tid + 256 * r] = keep[r];
   __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int j = tid + 256 * r;
-    if (j < n && s_chunk[j] == my_chunk && s_stamp[s_idx[j]] == j + 1) {
-      const float v = transformed(my_val[r]);
+#pragma unroll 1   // (one instance of the double-precision pow: the kernel stays within 56 registers, see the note above)
+  for (int j = tid; j < n; j += 256) {
+    if (s_chunk[j] == my_chunk && s_stamp[s_idx[j]] == j + 1) {
+      const float v = transformed(val[j]);
       s[chunk + s_idx[j]] = v;
       nodes[cap + leaf0 + s_idx[j]] = v;
     }
@@ -559,11 +570,14 @@ int hb_tree_create(int64_t capacity, hb_tree** out) {
   {
     const char* path = getenv("HB_TREE_UPDATE_PATH");
     t->single_wg = path && path[0] == 's';
+    t->fused_pow = !(path && path[0] == 't');
   }
+  t->small_scratch = nullptr;
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->nodes), 2 * cap * sizeof(float)), delete t);
   HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->errors), 8), { (void)hipFree(t->nodes); delete t; });
   HB_HIP_OR(hipMemset(t->nodes, 0, 2 * cap * sizeof(float)), hb_tree_destroy(t));
   HB_HIP_OR(hipMemset(t->errors, 0, 8), hb_tree_destroy(t));
+  HB_HIP_OR(hipMalloc(reinterpret_cast<void**>(&t->small_scratch), SMALL_MAX * sizeof(float)), hb_tree_destroy(t));
   *out = t;
   return HB_OK;
 }
@@ -574,6 +588,7 @@ int hb_tree_destroy(hb_tree* t) {
   if (t->errors) (void)hipFree(t->errors);
   if (t->stamp) (void)hipFree(t->stamp);
   if (t->scratch) (void)hipFree(t->scratch);
+  if (t->small_scratch) (void)hipFree(t->small_scratch);
   delete t;
   return HB_OK;
 }
@@ -587,8 +602,19 @@ static int update_impl(hb_tree* t, const int64_t* idx, const float* val, int64_t
   // (measured at cap 2^19, scripts/tree_probe.py: one workgroup 7.9 / 12.6 / 20.0 / 68 us at n = 32 / 128 / 256 / 1024;
   //  per-subtree workgroups 11-12 us flat)
   if (n >= 96 && n <= SMALL_MAX && t->cap >= 4 * static_cast<long long>(t->chunk) && !t->single_wg) {
-    hipLaunchKernelGGL(update_chunks_kernel, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
-                       idx, val, static_cast<int>(n), per_mode, alpha, max_prio, min_prio, t->errors);
+    if (per_mode && t->fused_pow) {
+      hipLaunchKernelGGL(update_chunks_kernel<true>, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
+                         idx, val, static_cast<int>(n), alpha, max_prio, min_prio, t->errors);
+    } else {
+      const float* v = val;
+      if (per_mode) {   // two small launches that both fit beside the policy kernel instead of one that does not
+        hipLaunchKernelGGL(per_transform_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, val, t->small_scratch,
+                           static_cast<long long>(n), alpha, max_prio, min_prio);
+        v = t->small_scratch;
+      }
+      hipLaunchKernelGGL(update_chunks_kernel<false>, dim3(static_cast<unsigned>(n + 1)), dim3(256), 0, s, t->nodes, t->cap, t->chunk,
+                         idx, v, static_cast<int>(n), 0.0, static_cast<float*>(nullptr), static_cast<float*>(nullptr), t->errors);
+    }
     if (!t->lazy_top) launch_top(t, s);
     HB_HIP(hipGetLastError());
     return HB_OK;

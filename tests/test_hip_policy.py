@@ -440,10 +440,13 @@ def test_relu_backward_with_column_sums_and_update_counter():
     assert a._fl.step.item() == 4 and a.train_step == 4
 
 
-def test_adam_multi_vector_path_equals_scalar_kernel():
-    """hb_noisy_adam_multi (four elements per thread, gradient read from a padded bf16 GEMM output) is bit-identical
-    to hb_noisy_adam (one element per thread, fp32 gradient) on the same data."""
+@pytest.mark.parametrize("width", ["4", "2", "1"])
+def test_adam_multi_vector_path_equals_scalar_kernel(width, monkeypatch):
+    """hb_noisy_adam_multi (four / two / one element per thread — HB_ADAM_WIDTH, csrc/learner.hip —, gradient read from a
+    padded bf16 GEMM output) is bit-identical to hb_noisy_adam (one element per thread, fp32 gradient) on the same data."""
     import torch
+
+    monkeypatch.setenv("HB_ADAM_WIDTH", width)
 
     from hanabi_hip import _capi as K
 

@@ -179,8 +179,12 @@ def test_per_sample_and_update_match_oracle_and_reference_golden():
             omx, omn = float(np.float32(omx)), float(np.float32(omn))
 
 
-def test_learner_sized_per_cycle_at_full_capacity():
-    """cap 2^19, B=256: stratified sample -> update, 50 rounds, exact vs the oracle."""
+@pytest.mark.parametrize("path", ["", "two"])
+def test_learner_sized_per_cycle_at_full_capacity(path, monkeypatch):
+    """cap 2^19, B=256: stratified sample -> update, 50 rounds, exact vs the oracle. Both forms of the small priority write-back
+    (csrc/sum_tree.hip: the transform inside update_chunks, or per_transform + update_chunks<false>: HB_TREE_UPDATE_PATH=two)."""
+    if path:
+        monkeypatch.setenv("HB_TREE_UPDATE_PATH", path)
     rng = np.random.default_rng(3)
     cap = 2 ** 19
     t, o = T(cap), O.OracleTree(cap)
