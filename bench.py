@@ -85,6 +85,7 @@ def _parse():
     ap.add_argument("--players", type=int, default=2)
     ap.add_argument("--n-step", type=int, default=1, help="n-step returns assembled at sample time (SURVEY 8(f)-2; the reference's agent is 1-step)")
     ap.add_argument("--no-nstep-variant", action="store_true", help="skip the second synchronous measurement with n_step = 3")
+    ap.add_argument("--no-fp16-variant", action="store_true", help="skip the synchronous measurement with fp16 GEMM operands")
     ap.add_argument("--updates-per-step", type=int, default=1)
     ap.add_argument("--compute-dtype", default="bfloat16", choices=list(MFMA_PEAK_TFLOPS))
     ap.add_argument("--games-per-wave", type=int, default=None, help="8/16/32/64; default: the library's choice")
@@ -566,18 +567,25 @@ def main():
             if args.compute_dtype in TOLERANCE:
                 line["tolerance"] = dict(TOLERANCE[args.compute_dtype], dtype=args.compute_dtype, reference="fp32 PyTorch-autograd path "
                                          "(DQNLearning.loss + Adam; DQNPolicy.q_values)", test="tests/test_dtype_parity.py")
-    if (session is not None and not args.vanilla and args.actor_lag == 0 and args.compute_dtype == "bfloat16"
+    if (session is not None and not args.vanilla and args.actor_lag == 0 and args.compute_dtype in ("bfloat16", "float16")
             and not args.no_async_variant and env.packed):
         session.flush()
         line["async_actor"] = async_variant(args, rank, world, device, n,   # (every rank: it holds collectives)
                                             streams=list(dict.fromkeys(session._lstreams.values())))
     if (session is not None and not args.vanilla and args.actor_lag == 0 and args.n_step == 1 and not args.no_nstep_variant
-            and env.packed and args.compute_dtype == "bfloat16"):
+            and env.packed and args.compute_dtype in ("bfloat16", "float16")):
         # north_star: "n-step double-DQN loss". The reference's rlax agent is 1-step (the headline); the n-step form it describes
         # (replay_memory.py:316-345) is timed beside it
         session.flush()
         line["n_step_3"] = async_variant(args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
                                          actor_lag=0, n_step=3)
+    if (session is not None and not args.vanilla and args.actor_lag == 0 and args.n_step == 1 and not args.no_fp16_variant
+            and env.packed and args.compute_dtype == "bfloat16"):
+        # the reference's own network dtype (rlax_rainbow.py:250-251: fp16) on the same kernels (v_mfma_f32_16x16x32_f16: the same
+        # MFMA rate; 8 x finer operand rounding: tolerance.py's float16 row instead of the bfloat16 one)
+        session.flush()
+        line["fp16_operands"] = async_variant(args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
+                                              actor_lag=0, n_step=1, dtype="float16")
     if rank == 0 and not args.no_cpu_baseline:
         note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)   # progress on stderr; stdout carries the ONE JSON line
         note(f"timed region done ({dt / args.steps * 1e3:.4f} ms per step); timing the CPU baselines on rank 0")
@@ -609,7 +617,7 @@ def main():
         dist.destroy_process_group()
 
 
-def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_step=None):
+def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_step=None, dtype=None):
     """The same workload with the asynchronous actor (RlaxRainbowParams.actor_lag = 1, one learner stream per
     agent), timed with the same protocol as the headline. Reported BESIDE the headline, which keeps the reference's
     synchronous semantics: here the policy acts on weights that are one update old (tests/test_async_actor.py)."""
@@ -620,8 +628,8 @@ def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_ste
     flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
     env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", args.players, flags), n_games=n, seed=1234,
                                first_game_id=rank * n, games_per_wave=args.games_per_wave, device=device, packed=True)
-    params = RlaxRainbowParams(compute_dtype=args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=True, actor_lag=actor_lag,
-                               n_step=args.n_step if n_step is None else n_step)
+    params = RlaxRainbowParams(compute_dtype=dtype or args.compute_dtype, mask_terminal=True, seed=1234 + rank, packed_obs=True,
+                               actor_lag=actor_lag, n_step=args.n_step if n_step is None else n_step)
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=1234 + 17 * s),
                        device=device) for s in range(args.players)]
     for a in agents:
@@ -663,7 +671,15 @@ def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_ste
     out = {"actor_lag": actor_lag, "n_step": params.n_step, "learner_streams": "one per agent", "ms_per_step": dt / args.steps * 1e3,
            "env_steps_per_sec": world * n * args.steps / dt, "grad_steps_per_sec": (session.grad_steps - g0) / dt,
            "host_enqueue_ms_per_step": host_s / args.steps * 1e3}
-    if actor_lag:
+    if dtype:
+        from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
+
+        out["compute_dtype"] = dtype
+        out["host_calls"] = {"steps_through_hb_chain_run": session.native_steps}
+        out["tolerance"] = {k: TOLERANCE[dtype][k] for k in ("q_abs", "argmax_gap", "td_abs", "td_rel")}
+        out["note"] = ("synchronous agent, the headline's protocol with fp16 GEMM operands (weights and hidden activations; fp32 "
+                       "accumulation, master weights, softmax and loss as before): the reference's own network dtype")
+    elif actor_lag:
         out["note"] = ("policy acts on the weights of the update before last (one-update staleness, tests/test_async_actor.py); "
                        "not the headline: the reference's agent is synchronous")
     else:
@@ -708,26 +724,28 @@ def qnet_roofline(agent, env, args):
         from hanabi_hip import _capi as K
 
         ac, L, s = fl0.actor, K.lib(), K.current_stream()
-        if ac._two_stale[0]:
-            ac._pack_two(0)   # (the two-kernel form's weight copies are refreshed lazily since round 3)
         obs8, legal8, support = env.net_obs, env.legal, agent.atoms[0].contiguous()
         acts = torch.empty(n, dtype=torch.int32, device=legal8.device)
-        hidden_fn = L.hb_actor_hidden_packed if env.packed else L.hb_actor_hidden
-        launches = {
-            "hb_actor_hidden": lambda: hidden_fn(K.dptr(obs8), n, ac.obs_len, K.dptr(ac.w1t), ac.k_pad, K.dptr(ac.b1), ac.hidden,
-                                                 K.dptr(ac.h), s),
-            "hb_actor_q": lambda: L.hb_actor_q(K.dptr(ac.h), n, ac.hidden, K.dptr(ac.w2t), K.dptr(ac.b2), K.dptr(support), ac.n_actions,
-                                               ac.n_atoms, K.dptr(ac.q), s),
-            "hb_policy_select": lambda: L.hb_policy_select(K.dptr(ac.q), K.dptr(legal8), n, ac.n_actions, 0.1, 1, 1, 0, K.dptr(acts), s),
-        }
-        flops = {"hb_actor_hidden": 2.0 * ac.k_pad * ac.hidden * n, "hb_actor_q": 2.0 * ac.hidden * ac.w2t.shape[0] * n}
+        launches, flops = {}, {}
+        if ac.two_kernel:   # (bf16 operands; fp16 has the one-kernel form only)
+            if ac._two_stale[0]:
+                ac._pack_two(0)   # (the two-kernel form's weight copies are refreshed lazily since round 3)
+            hidden_fn = L.hb_actor_hidden_packed if env.packed else L.hb_actor_hidden
+            launches = {
+                "hb_actor_hidden": lambda: hidden_fn(K.dptr(obs8), n, ac.obs_len, K.dptr(ac.w1t), ac.k_pad, K.dptr(ac.b1), ac.hidden,
+                                                     K.dptr(ac.h), s),
+                "hb_actor_q": lambda: L.hb_actor_q(K.dptr(ac.h), n, ac.hidden, K.dptr(ac.w2t), K.dptr(ac.b2), K.dptr(support), ac.n_actions,
+                                                   ac.n_atoms, K.dptr(ac.q), s),
+                "hb_policy_select": lambda: L.hb_policy_select(K.dptr(ac.q), K.dptr(legal8), n, ac.n_actions, 0.1, 1, 1, 0, K.dptr(acts), s),
+            }
+            flops = {"hb_actor_hidden": 2.0 * ac.k_pad * ac.hidden * n, "hb_actor_q": 2.0 * ac.hidden * ac.w2t.shape[0] * n}
         if ac.takes_fused(obs8):
             # round 3: the whole forward + selection as ONE kernel (csrc/actor_fused.hip): what the loop runs
             f = ac._fset_ptrs[0]
             n_pass = (ac.n_actions + 9) // 10
-            launches = dict({"hb_actor_fused_act": lambda: L.hb_actor_fused_act(
+            launches = dict({"hb_actor_fused_act": lambda: L.hb_actor_fused_act_dt(
                 K.dptr(obs8), K.dptr(legal8), n, ac.obs_len, f[0], f[1], f[2], f[3], K.dptr(support), ac.hidden, ac.n_actions, ac.n_atoms,
-                K.dptr(ac.q), 0.1, 1, 1, 0, K.dptr(acts), s)}, **launches)
+                K.dptr(ac.q), 0.1, 1, 1, 0, K.dptr(acts), ac._dt, s)}, **launches)
             flops["hb_actor_fused_act"] = 2.0 * n * (ac.k_pad * ac.hidden + ac.hidden * 512 * n_pass)
         per_kernel = {}
         for name, fn in launches.items():
@@ -748,7 +766,8 @@ def qnet_roofline(agent, env, args):
     fl = getattr(agent, "_fl", None)
     mfma_actor = fl is not None and fl.actor is not None and agent.use_mfma_actor
     kp = -(-env.obs_len // 64) * 64
-    ncols = fl.actor.w2t.shape[0] if mfma_actor else -(-env.num_actions * agent.params.n_atoms // 64) * 64
+    ncols = (fl.actor.w2t.shape[0] if mfma_actor and fl.actor.two_kernel else
+             512 * ((env.num_actions + 9) // 10) if mfma_actor else -(-env.num_actions * agent.params.n_atoms // 64) * 64)
     if not agent.distributional:
         ncols = env.num_actions
     exec_flop = 2.0 * (kp * hidden + hidden * ncols)

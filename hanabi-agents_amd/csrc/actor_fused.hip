@@ -25,6 +25,7 @@
 // Roofline: MFMA (bf16 dense 2.5 PFLOP/s); executed 58.0 GFLOP at 32 768 x 658 -> 512 -> 1 020.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 #include <cstdint>
 
@@ -37,6 +38,7 @@ using hb::fail;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FM = 128;                 // rows per workgroup
@@ -97,20 +99,40 @@ struct FusedArgs {
 #define HB_FSTAMP_REAL(slot) do {} while (0)
 #endif
 
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-  return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) |
-         (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+// The kernel exists for two operand types of the same MFMA rate: bf16 (F16 = false; v_mfma_f32_16x16x32_bf16) and fp16 (F16 = true;
+// v_mfma_f32_16x16x32_f16 — the reference's own network dtype, rlax_rainbow.py:250-251). Fragments travel as raw 16 bytes; only
+// the table of 0.0 / 1.0, the rounding of H and the MFMA itself know the type.
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16(float lo, float hi) {
+  if constexpr (F16) {
+    const _Float16 a = static_cast<_Float16>(lo), b = static_cast<_Float16>(hi);   // round to nearest even
+    uint16_t ua, ub;
+    __builtin_memcpy(&ua, &a, 2);
+    __builtin_memcpy(&ub, &b, 2);
+    return static_cast<uint32_t>(ua) | (static_cast<uint32_t>(ub) << 16);
+  } else {
+    const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+    return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) |
+           (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+  }
 }
-// two observation bits -> two bf16 0.0 / 1.0 (0x3F80)
-__device__ __forceinline__ uint32_t bits2_bf16(uint32_t b, int p) {
+// two observation bits -> two 16-bit floats 0.0 / 1.0 (bf16 0x3F80, fp16 0x3C00)
+template <bool F16>
+__device__ __forceinline__ uint32_t bits2_one(uint32_t b, int p) {
   const uint32_t t = (b >> (2 * p)) & 3u;
-  return __umul24((t | (t << 15)) & 0x00010001u, 0x3F80u);
+  return __umul24((t | (t << 15)) & 0x00010001u, F16 ? 0x3C00u : 0x3F80u);
 }
-__device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
-  union { uint4 u; bf16x8 f; } c;
-  c.u = v;
-  return c.f;
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& wv, const uint4& xv, const f32x4& c) {
+  if constexpr (F16) {
+    union { uint4 u; f16x8 f; } w, x;
+    w.u = wv; x.u = xv;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w.f, x.f, c, 0, 0, 0);
+  } else {
+    union { uint4 u; bf16x8 f; } w, x;
+    w.u = wv; x.u = xv;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f, x.f, c, 0, 0, 0);
+  }
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -131,6 +153,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 }
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
+template <bool F16>
 __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_TOTAL];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
   // ---- table: entry (v, slot) at v * 256 + slot * 16
   for (int e = tid; e < 4096; e += FNT) {
     const uint32_t v = static_cast<uint32_t>(e) >> 4;
-    *reinterpret_cast<uint4*>(lutb + e * 16) = make_uint4(bits2_bf16(v, 0), bits2_bf16(v, 1), bits2_bf16(v, 2), bits2_bf16(v, 3));
+    *reinterpret_cast<uint4*>(lutb + e * 16) = make_uint4(bits2_one<F16>(v, 0), bits2_one<F16>(v, 1), bits2_one<F16>(v, 2), bits2_one<F16>(v, 3));
   }
   for (int it = tid; it < FM * G; it += FNT) {
     const int rr = it & (FM - 1), g = it >> 7;
@@ -204,15 +227,14 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
       _Pragma("unroll") for (int n = 0; n < 4; ++n) WNXT[n] = w1p[(s_ + 1) * 2048 + n * 64];                    \
     }                                                                                                          \
     asm volatile("" ::: "memory"); /* the loads are ISSUED here, a whole step before their use */               \
-    bf16x8 xf[8];                                                                                              \
+    uint4 xf[8];                                                                                               \
     _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                            \
       const uint32_t v = (xw[m] >> (8 * (I))) & 0xFFu;                                                         \
-      xf[m] = *reinterpret_cast<const bf16x8*>(lut + v * 256u);                                                \
+      xf[m] = *reinterpret_cast<const uint4*>(lut + v * 256u);                                                 \
     }                                                                                                          \
     _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                            \
-      const bf16x8 wf = as_frag(WCUR[n]);                                                                      \
       _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                            \
-        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[n][m], 0, 0, 0);                    \
+        acc[n][m] = mfma16<F16>(WCUR[n], xf[m], acc[n][m]);                                                    \
     }                                                                                                          \
   }
     for (int g = 0; g < G; ++g) {
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
         const float v0 = fmaxf(acc[n][m][0], 0.f), v1 = fmaxf(acc[n][m][1], 0.f);                               \
         const float v2 = fmaxf(acc[n][m][2], 0.f), v3 = fmaxf(acc[n][m][3], 0.f);                               \
         *reinterpret_cast<uint2*>(lds + (16 * m + r) * 1024 + ((chunk ^ r) << 4) + (qd & 1) * 8) =              \
-            make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));                                                   \
+            make_uint2(pack16<F16>(v0, v1), pack16<F16>(v2, v3));                                               \
       }                                                                                                         \
     }                                                                                                           \
   }
@@ -284,13 +306,12 @@ __global__ __launch_bounds__(FNT) void actor_fused_kernel(const FusedArgs a) {
 // forward kernels (36-47 registers) then run on the same CUs while this kernel holds them (DESIGN: co-residency).
 #define HB_L2_HALF(S, WCUR, M0)                                                                                \
   {                                                                                                            \
-    bf16x8 xf[4];                                                                                              \
+    uint4 xf[4];                                                                                               \
     const int ch = ((4 * (S) + qd) ^ r) << 4;                                                                  \
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(hrow + ((M0) + m) * 16384 + ch); \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const uint4*>(hrow + ((M0) + m) * 16384 + ch); \
     _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                            \
-      const bf16x8 wf = as_frag(WCUR[n]);                                                                      \
       _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                            \
-        acc[n][(M0) + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[n][(M0) + m], 0, 0, 0);      \
+        acc[n][(M0) + m] = mfma16<F16>(WCUR[n], xf[m], acc[n][(M0) + m]);                                      \
     }                                                                                                          \
   }
 #define HB_L2_STEP(S, WCUR, WNXT, HAVE_NEXT)                                                                   \
@@ -527,7 +548,11 @@ struct PackArgs {
   int obs_len, s1, n_actions, n_pass;
   uint4* w1f; float* b1f; uint4* w2f; float* b2f;
   int chunks1, chunks2;   // 16-byte chunks of w1f / w2f
+  int f16;                // the 16-bit elements are fp16 (only the biases are converted: the weights are copied as they are)
 };
+__device__ __forceinline__ float bias_to_float(const __hip_bfloat16* b, int i, int f16) {
+  return f16 ? __half2float(reinterpret_cast<const __half*>(b)[i]) : __bfloat162float(b[i]);
+}
 // physical column -> logit index (action * 51 + atom) or -1
 __device__ __forceinline__ int fused_logit(int col, int n_actions, int n_pass) {
   const int slot = col >> 6, c = col & 63, n = c >> 4, q = (c >> 2) & 3, j = c & 3;
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(256) void actor_fused_pack_kernel(const PackArgs a)
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (k0 + i < a.obs_len) ? a.w1[static_cast<long long>(k0 + i) * a.w1_ld + unit] : zero;
     a.w1f[id] = *reinterpret_cast<const uint4*>(v);
-    if (id < FH) a.b1f[id] = __bfloat162float(a.b1[id]);
+    if (id < FH) a.b1f[id] = bias_to_float(a.b1, id, a.f16);
   } else if (id < a.chunks1 + a.chunks2) {
     const int id2 = id - a.chunks1;
     const int lane = id2 & 63, ntp = (id2 >> 6) & 31, s = (id2 >> 11) % S2, pass = (id2 >> 11) / S2;
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(256) void actor_fused_pack_kernel(const PackArgs a)
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = lg >= 0 ? a.w2[static_cast<long long>(k0 + i) * a.w2_ld + lg] : zero;
     a.w2f[id2] = *reinterpret_cast<const uint4*>(v);
-    if (s == 0 && (lane >> 4) == 0) a.b2f[col] = lg >= 0 ? __bfloat162float(a.b2[lg]) : NEG_BIG;
+    if (s == 0 && (lane >> 4) == 0) a.b2f[col] = lg >= 0 ? bias_to_float(a.b2, lg, a.f16) : NEG_BIG;
   }
 }
 
@@ -591,9 +616,10 @@ int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int
   return HB_OK;
 }
 
-int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld, const void* b2_dev,
-                        int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev, float* b1f_dev, void* w2f_dev,
-                        float* b2f_dev, void* stream) {
+int hb_actor_fused_pack_dt(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld, const void* b2_dev,
+                           int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev, float* b1f_dev,
+                           void* w2f_dev, float* b2f_dev, int32_t dtype, void* stream) {
+  if (dtype != 1 && dtype != 2) return fail(HB_ERR_INVALID, "dtype must be 1 (bf16) or 2 (f16)");
   if (!w1_dev || !b1_dev || !w2_dev || !b2_dev || !w1f_dev || !b1f_dev || !w2f_dev || !b2f_dev) return fail(HB_ERR_INVALID, "null argument");
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
   if (w1_ld < hidden || w2_ld < n_actions * n_atoms) return fail(HB_ERR_INVALID, "row strides shorter than the rows");
@@ -604,10 +630,18 @@ int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, c
   p.obs_len = obs_len; p.s1 = 2 * ((obs_len + 63) / 64); p.n_actions = n_actions; p.n_pass = passes_for(n_actions);
   p.w1f = static_cast<uint4*>(w1f_dev); p.b1f = b1f_dev; p.w2f = static_cast<uint4*>(w2f_dev); p.b2f = b2f_dev;
   p.chunks1 = 32 * p.s1 * 64; p.chunks2 = 32 * p.n_pass * S2 * 64;
+  p.f16 = dtype == 2 ? 1 : 0;
   const int blocks = (p.chunks1 + p.chunks2 + 255) / 256;
   hipLaunchKernelGGL(actor_fused_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   HB_HIP(hipGetLastError());
   return HB_OK;
+}
+
+int hb_actor_fused_pack(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld, const void* b2_dev,
+                        int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev, float* b1f_dev, void* w2f_dev,
+                        float* b2f_dev, void* stream) {
+  return hb_actor_fused_pack_dt(w1_dev, w1_ld, b1_dev, w2_dev, w2_ld, b2_dev, obs_len, hidden, n_actions, n_atoms, w1f_dev, b1f_dev,
+                                w2f_dev, b2f_dev, 1, stream);
 }
 
 struct FusedSelect {
@@ -619,24 +653,39 @@ struct FusedSelect {
 };
 static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                         const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
-                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, void* stream);
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, int32_t dtype, void* stream);
+
+int hb_actor_fused_q_dt(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                        const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                        int32_t n_atoms, float* q_dev, int32_t dtype, void* stream) {
+  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
+                      nullptr, nullptr, dtype, stream);
+}
+
+int hb_actor_fused_act_dt(const uint32_t* obs_bits_dev, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev,
+                          const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
+                          int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
+                          int64_t first_game_id, int32_t* actions_dev, int32_t dtype, void* stream) {
+  if (!legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64 for the fused selection");
+  const FusedSelect sel{legal_dev, actions_dev, epsilon, seed, draw, first_game_id};
+  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
+                      nullptr, &sel, dtype, stream);
+}
 
 int hb_actor_fused_q(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                      const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions, int32_t n_atoms,
                      float* q_dev, void* stream) {
   return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
-                      nullptr, nullptr, stream);
+                      nullptr, nullptr, 1, stream);
 }
 
 int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev,
                        const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
                        int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
                        int64_t first_game_id, int32_t* actions_dev, void* stream) {
-  if (!legal_dev || !actions_dev) return fail(HB_ERR_INVALID, "null argument");
-  if (n_actions > 64) return fail(HB_ERR_INVALID, "n_actions must be 1..64 for the fused selection");
-  const FusedSelect sel{legal_dev, actions_dev, epsilon, seed, draw, first_game_id};
-  return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
-                      nullptr, &sel, stream);
+  return hb_actor_fused_act_dt(obs_bits_dev, legal_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden,
+                               n_actions, n_atoms, q_dev, epsilon, seed, draw, first_game_id, actions_dev, 1, stream);
 }
 
 #ifdef HB_STAMPS
@@ -645,13 +694,14 @@ int hb_actor_fused_q_stamped(const uint32_t* obs_bits_dev, int64_t n_rows, int32
                              const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
                              int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, void* stream) {
   return fused_launch(obs_bits_dev, n_rows, obs_len, w1f_dev, b1f_dev, w2f_dev, b2f_dev, support_dev, hidden, n_actions, n_atoms, q_dev,
-                      stamps_dev, nullptr, stream);
+                      stamps_dev, nullptr, 1, stream);
 }
 #endif
 
 static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                         const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
-                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, void* stream) {
+                        int32_t n_atoms, float* q_dev, unsigned long long* stamps_dev, const FusedSelect* sel, int32_t dtype, void* stream) {
+  if (dtype != 1 && dtype != 2) return fail(HB_ERR_INVALID, "dtype must be 1 (bf16) or 2 (f16)");
   if (!obs_bits_dev || !w1f_dev || !b1f_dev || !w2f_dev || !b2f_dev || !support_dev || !q_dev) return fail(HB_ERR_INVALID, "null argument");
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
   if (n_rows <= 0) return HB_OK;
@@ -667,7 +717,8 @@ static int fused_launch(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t ob
     a.first_gid = sel->first_gid;
   }
   const dim3 grid(static_cast<unsigned>((n_rows + FM - 1) / FM));
-  hipLaunchKernelGGL(actor_fused_kernel, grid, dim3(FNT), 0, static_cast<hipStream_t>(stream), a);
+  if (dtype == 2) hipLaunchKernelGGL(actor_fused_kernel<true>, grid, dim3(FNT), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(actor_fused_kernel<false>, grid, dim3(FNT), 0, static_cast<hipStream_t>(stream), a);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

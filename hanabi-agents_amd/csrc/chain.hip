@@ -47,12 +47,13 @@ int hb_chain_run(const hb_cmd* cmds, int32_t count, const int64_t* vars_i, const
         break;
       case HB_CMD_ACTOR_FUSED_ACT:   // vars_i[var] = draw counter, vars_f[fvar] = epsilon
         if (!vi || !vf) return fail(HB_ERR_INVALID, "command %d: hb_actor_fused_act needs its draw and epsilon variables", k);
-        rc = hb_actor_fused_act(static_cast<const uint32_t*>(c.p[0]), static_cast<const int8_t*>(c.p[1]), c.i[0],
-                                static_cast<int32_t>(c.i[1]), c.p[2], static_cast<const float*>(c.p[3]), c.p[4],
-                                static_cast<const float*>(c.p[5]), static_cast<const float*>(c.p[6]), static_cast<int32_t>(c.i[2]),
-                                static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]), static_cast<float*>(c.p[7]),
-                                static_cast<float>(vf[0]), static_cast<uint64_t>(c.i[5]), static_cast<uint64_t>(vi[0]), c.i[6],
-                                static_cast<int32_t*>(c.p[8]), c.stream);
+        // i[7]: operand dtype of the weight copies (0 or 1 = bf16, 2 = f16): hb_actor_fused_act_dt
+        rc = hb_actor_fused_act_dt(static_cast<const uint32_t*>(c.p[0]), static_cast<const int8_t*>(c.p[1]), c.i[0],
+                                   static_cast<int32_t>(c.i[1]), c.p[2], static_cast<const float*>(c.p[3]), c.p[4],
+                                   static_cast<const float*>(c.p[5]), static_cast<const float*>(c.p[6]), static_cast<int32_t>(c.i[2]),
+                                   static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]), static_cast<float*>(c.p[7]),
+                                   static_cast<float>(vf[0]), static_cast<uint64_t>(c.i[5]), static_cast<uint64_t>(vi[0]), c.i[6],
+                                   static_cast<int32_t*>(c.p[8]), c.i[7] == 2 ? 2 : 1, c.stream);
         break;
       case HB_CMD_ENV_STEP_PACKED:
         rc = hb_env_step_packed(static_cast<hb_env*>(c.p[0]), static_cast<const int32_t*>(c.p[1]), static_cast<uint32_t*>(c.p[2]),
@@ -83,10 +84,11 @@ int hb_chain_run(const hb_cmd* cmds, int32_t count, const int64_t* vars_i, const
                            c.f[0], static_cast<float*>(c.p[3]), static_cast<float*>(c.p[4]), c.stream);
         break;
       case HB_CMD_ACTOR_FUSED_PACK:
-        rc = hb_actor_fused_pack(c.p[0], static_cast<int32_t>(c.i[0]), c.p[1], c.p[2], static_cast<int32_t>(c.i[1]), c.p[3],
-                                 static_cast<int32_t>(c.i[2]), static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]),
-                                 static_cast<int32_t>(c.i[5]), c.p[4], static_cast<float*>(c.p[5]), c.p[6], static_cast<float*>(c.p[7]),
-                                 c.stream);
+        // i[6]: dtype of the 16-bit operands (0 or 1 = bf16, 2 = f16): hb_actor_fused_pack_dt
+        rc = hb_actor_fused_pack_dt(c.p[0], static_cast<int32_t>(c.i[0]), c.p[1], c.p[2], static_cast<int32_t>(c.i[1]), c.p[3],
+                                    static_cast<int32_t>(c.i[2]), static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]),
+                                    static_cast<int32_t>(c.i[5]), c.p[4], static_cast<float*>(c.p[5]), c.p[6], static_cast<float*>(c.p[7]),
+                                    c.i[6] == 2 ? 2 : 1, c.stream);
         break;
       case HB_CMD_ACTOR_PACK_WEIGHTS:   // p[0]: the caller's hb_pack_job array (host memory that outlives the chain), i[0]: count
         rc = hb_actor_pack_weights(static_cast<const hb_pack_job*>(c.p[0]), static_cast<int32_t>(c.i[0]), c.stream);

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(const T* __restrict__ q_o
 // (scripts/thin_probe.py: it finishes inside a running hb_actor_q and lengthens that GEMM by 3 %).
 //   out[b][m, n] = act(sum_k x[b][m, k] * wt[b][n, k] + bias[n]),  x and wt k-contiguous bf16, fp32 accumulation in k order
 typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tg_f16x8 __attribute__((ext_vector_type(8)));
 typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 struct ThinArgs {
   const unsigned char* x;    // bf16 [batch][M][ldx]
@@ -579,14 +580,42 @@ struct ThinArgs {
   void* out;                 // [batch][M][ldo], bf16 or (relu & 2) fp32
   unsigned ldx, ldw, ldo;    // in elements
   unsigned x_bs, w_bs, o_bs; // batch strides in elements
-  int k, relu;             // relu: bit 0 = ReLU, bit 1 = fp32 output
+  int k, relu;             // relu: bit 0 = ReLU, bit 1 = fp32 output (bit 2, fp16 operands, selects the kernel instantiation)
   unsigned n_tiles;        // first column tile (16 columns each) this launch covers
   unsigned nb;             // elements between the bias rows of consecutive batch entries (= n)
 };
+// F16: x, wt, bias and a 16-bit output are fp16 instead of bf16 (v_mfma_f32_16x16x32_f16: same rate)
+template <bool F16>
 __device__ __forceinline__ uint32_t tg_pack(float lo, float hi) {
-  const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-  return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+  if constexpr (F16) {
+    const _Float16 a = static_cast<_Float16>(lo), b = static_cast<_Float16>(hi);
+    uint16_t ua, ub;
+    __builtin_memcpy(&ua, &a, 2);
+    __builtin_memcpy(&ub, &b, 2);
+    return static_cast<uint32_t>(ua) | (static_cast<uint32_t>(ub) << 16);
+  } else {
+    const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+    return static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&a)) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+  }
 }
+template <bool F16>
+__device__ __forceinline__ float tg_bias(const __hip_bfloat16* b, unsigned i) {
+  if constexpr (F16) return __half2float(reinterpret_cast<const __half*>(b)[i]);
+  else return __bfloat162float(b[i]);
+}
+template <bool F16>
+__device__ __forceinline__ tg_f32x4 tg_mfma(const uint4& wv, const uint4& xv, const tg_f32x4& c) {
+  if constexpr (F16) {
+    union { uint4 u; tg_f16x8 f; } w, x;
+    w.u = wv; x.u = xv;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w.f, x.f, c, 0, 0, 0);
+  } else {
+    union { uint4 u; tg_bf16x8 f; } w, x;
+    w.u = wv; x.u = xv;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f, x.f, c, 0, 0, 0);
+  }
+}
+template <bool F16>
 __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const int batch) {
   // One wavefront per (row tile, column tile); it walks the batch itself, so a launch never has more workgroups than
   // (m / 32) * (n / 16): for the learner's shapes that is 1 024 = one wavefront per SIMD of the chip, which leaves an
@@ -601,17 +630,17 @@ __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const i
     float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     if (a.bias) {
       const __hip_bfloat16* bz = a.bias + static_cast<size_t>(z) * a.nb;
-      b0 = __bfloat162float(bz[c]); b1 = __bfloat162float(bz[c + 1]); b2 = __bfloat162float(bz[c + 2]); b3 = __bfloat162float(bz[c + 3]);
+      b0 = tg_bias<F16>(bz, c); b1 = tg_bias<F16>(bz, c + 1); b2 = tg_bias<F16>(bz, c + 2); b3 = tg_bias<F16>(bz, c + 3);
     }
     const unsigned xo = (z * a.x_bs + (blockIdx.x * 32u + lr) * a.ldx + kq * 8u) * 2u;
     const unsigned wo = (z * a.w_bs + (ct * 16u + lr) * a.ldw + kq * 8u) * 2u;
     tg_f32x4 acc0 = tg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll 1
     for (unsigned kb = 0; kb < static_cast<unsigned>(a.k) * 2u; kb += 64u) {
-      const tg_bf16x8 x0 = *reinterpret_cast<const tg_bf16x8*>(a.x + xo + kb), x1 = *reinterpret_cast<const tg_bf16x8*>(a.x + xo + kb + half);
-      const tg_bf16x8 w0 = *reinterpret_cast<const tg_bf16x8*>(a.wt + wo + kb);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x1, acc1, 0, 0, 0);
+      const uint4 x0 = *reinterpret_cast<const uint4*>(a.x + xo + kb), x1 = *reinterpret_cast<const uint4*>(a.x + xo + kb + half);
+      const uint4 w0 = *reinterpret_cast<const uint4*>(a.wt + wo + kb);
+      acc0 = tg_mfma<F16>(w0, x0, acc0);
+      acc1 = tg_mfma<F16>(w0, x1, acc1);
     }
     // acc_m[j] = out[row 32 bx + 16 m + (lane & 15)][col 16 by + 4 (lane >> 4) + j]
     float v[8] = {acc0[0] + b0, acc0[1] + b1, acc0[2] + b2, acc0[3] + b3, acc1[0] + b0, acc1[1] + b1, acc1[2] + b2, acc1[3] + b3};
@@ -626,8 +655,8 @@ __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const i
       *reinterpret_cast<float4*>(o + 16u * static_cast<size_t>(a.ldo)) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
       __hip_bfloat16* o = static_cast<__hip_bfloat16*>(a.out) + oo;
-      *reinterpret_cast<uint2*>(o) = make_uint2(tg_pack(v[0], v[1]), tg_pack(v[2], v[3]));
-      *reinterpret_cast<uint2*>(o + 16u * static_cast<size_t>(a.ldo)) = make_uint2(tg_pack(v[4], v[5]), tg_pack(v[6], v[7]));
+      *reinterpret_cast<uint2*>(o) = make_uint2(tg_pack<F16>(v[0], v[1]), tg_pack<F16>(v[2], v[3]));
+      *reinterpret_cast<uint2*>(o + 16u * static_cast<size_t>(a.ldo)) = make_uint2(tg_pack<F16>(v[4], v[5]), tg_pack<F16>(v[6], v[7]));
     }
   }
 }
@@ -673,7 +702,7 @@ int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, vo
   if (m <= 0 || n <= 0 || batch <= 0) return HB_OK;
   if (m % 32 || n % 16 || k % 32 || k < 32) return fail(HB_ERR_INVALID, "need m % 32 == 0, n % 16 == 0, k % 32 == 0");
   if (ldx < k || ldw < k || ldo < n || ldx % 8 || ldw % 8 || ldo % 4) return fail(HB_ERR_INVALID, "bad leading dimensions");
-  if (relu < 0 || relu > 3) return fail(HB_ERR_INVALID, "relu: bit 0 = ReLU, bit 1 = fp32 output");
+  if (relu < 0 || relu > 7) return fail(HB_ERR_INVALID, "relu: bit 0 = ReLU, bit 1 = fp32 output, bit 2 = fp16 (not bf16) operands");
   if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) || (reinterpret_cast<uintptr_t>(wt_dev) & 15u) ||
       (reinterpret_cast<uintptr_t>(out_dev) & ((relu & 2) ? 15u : 7u)))
     return fail(HB_ERR_ALIGN, "x / wt must be 16-byte aligned, out 8-byte (fp32 output: 16-byte) aligned");
@@ -688,8 +717,9 @@ int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, vo
   const unsigned tiles = static_cast<unsigned>(n / 16), gx = static_cast<unsigned>(m / 32), cap = gx >= 1024u ? 1u : 1024u / gx;
   for (unsigned t0 = 0; t0 < tiles; t0 += cap) {
     a.n_tiles = t0;
-    hipLaunchKernelGGL(thin_gemm_kernel, dim3(gx, tiles - t0 < cap ? tiles - t0 : cap), dim3(64), 0, static_cast<hipStream_t>(stream), a,
-                       batch);
+    const dim3 grid(gx, tiles - t0 < cap ? tiles - t0 : cap);
+    if (relu & 4) hipLaunchKernelGGL(thin_gemm_kernel<true>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+    else hipLaunchKernelGGL(thin_gemm_kernel<false>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
   }
   HB_HIP(hipGetLastError());
   return HB_OK;

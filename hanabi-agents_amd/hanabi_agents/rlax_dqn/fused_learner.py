@@ -64,7 +64,7 @@ class FusedLearner:
         # "thin" forward (bf16): the two dense layers on hb_thin_gemm, a kernel small enough to run on the CUs WHILE the other
         # seat's actor GEMMs hold them (a library GEMM would wait for those to retire). It reads the weights TRANSPOSED
         # (k-contiguous): copies kept current by one hb_actor_pack_weights launch after every optimizer step / target sync.
-        self.thin = (self.cd == torch.bfloat16 and os.environ.get("HB_THIN_LEARNER", "1") != "0" and self.Kp % 32 == 0
+        self.thin = (self.cd in (torch.bfloat16, torch.float16) and os.environ.get("HB_THIN_LEARNER", "1") != "0" and self.Kp % 32 == 0
                      and H % 64 == 0 and self.Np % 16 == 0 and (2 * B) % 32 == 0)
         if self.thin:
             self.w1catT = torch.zeros(2 * H, self.Kp, dtype=self.cd, device=dev)
@@ -132,8 +132,8 @@ class FusedLearner:
         self.n_packed = 0
         self._packed_in_part2 = False
         self.packed_ev = [None, None]
-        if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd) and getattr(agent, "use_mfma_actor", True):
-            self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev, n_sets=2 if self.lag else 1)
+        if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd, self.A) and getattr(agent, "use_mfma_actor", True):
+            self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev, n_sets=2 if self.lag else 1, dtype=self.cd)
         if self.lag and (self.actor is None or not agent.params.use_priority or agent.params.resample_noise):
             raise ValueError("actor_lag=1 needs the MFMA actor (bf16 GEMM dtype, one hidden layer of a multiple of 256 units), "
                              "prioritized replay and frozen noise")
@@ -264,10 +264,11 @@ class FusedLearner:
             # the transposed online weights are refreshed HERE (not right after Adam): the acting stream does not wait for
             # it, and like the two GEMMs below the small transposer runs beside the other seat's policy GEMMs
             self._transpose(0)
+            f16 = 4 if self.cd == torch.float16 else 0   # (hb_thin_gemm: bit 2 of its flags = fp16 operands)
             K.check(L.hb_thin_gemm(K.dptr(self.x), K.dptr(self.w1catT), K.dptr(self.b1cat), K.dptr(hcat), 2 * B, 2 * H, self.Kp,
-                                   self.Kp, self.Kp, 2 * H, 1, 0, 0, 0, 1, s))                       # bias + ReLU, [2B, 2H]
+                                   self.Kp, self.Kp, 2 * H, 1, 0, 0, 0, 1 | f16, s))                 # bias + ReLU, [2B, 2H]
             K.check(L.hb_thin_gemm(K.dptr(hcat), K.dptr(self.w2stT), K.dptr(self.b2st), K.dptr(logits), 2 * B, self.Np, H, 2 * H, H,
-                                   self.Np, 2, H, self.Np * H, 2 * B * self.Np, 2, s))               # {online, target}: [2, 2B, Np] fp32, biases added
+                                   self.Np, 2, H, self.Np * H, 2 * B * self.Np, 2 | f16, s))         # {online, target}: [2, 2B, Np] fp32, biases added
         else:
             hcat = torch._addmm_activation(self.b1cat, self.x, self.w1cat, use_gelu=False)   # bias + ReLU in the epilogue, [2B, 2H]
             logits = torch.bmm(hcat.view(2 * B, 2, H).transpose(0, 1), self.w2st)            # [2, 2B, Np], strided A operand: no copy

@@ -345,7 +345,7 @@ class DQNAgent:
         self._wait_for_weights()
         eff = self._effective_weights()
         fl = self._fused_learner() if self.actor_lag else self._fl
-        if fl is not None and fl.actor is not None and obs.dtype in (torch.int8, torch.int32) and self.use_mfma_actor:
+        if fl is not None and fl.actor is not None and self.use_mfma_actor and fl.actor.accepts(obs):
             # hand-written MFMA path: int8 or bit-packed observations in, actions out; no bf16 copy of the observations and no
             # logits in HBM
             wset = fl.acting_set()
@@ -383,7 +383,7 @@ class DQNAgent:
         if not isinstance(obs, torch.Tensor) or obs.device != self.device:
             obs = self._unpack(observations)[0]
         fl = self._fused_learner() if self.actor_lag else self._fl
-        if fl is None or fl.actor is None or obs.dtype not in (torch.int8, torch.int32):
+        if fl is None or fl.actor is None or not fl.actor.accepts(obs):
             return None
         self._wait_for_weights()
         wset = fl.acting_set()

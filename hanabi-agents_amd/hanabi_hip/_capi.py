@@ -162,6 +162,9 @@ SIGNATURES = {
     "hb_actor_fused_pack": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "hb_actor_fused_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "hb_actor_fused_act": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_float, _U64, _U64, _I64, _P, _P]),
+    "hb_actor_fused_pack_dt": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P]),
+    "hb_actor_fused_q_dt": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P]),
+    "hb_actor_fused_act_dt": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_float, _U64, _U64, _I64, _P, _I32, _P]),
     "hb_chain_run": (C.c_int, [C.POINTER(HbCmd), _I32, C.POINTER(_I64), C.POINTER(_F64)]),
     "hb_relu_bwd_colsum": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P]),
     "hb_replay_insert": (C.c_int, [_P] * 12 + [_I64, _I32, _I32, _I64, _I64, _P]),

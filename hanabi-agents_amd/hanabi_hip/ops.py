@@ -67,18 +67,23 @@ class ActorMFMA:
     """The actor's forward pass on the hand-written MFMA kernels (csrc/actor.hip): packed (transposed) copies of
     the effective weights plus the scratch buffers; `pack` after every weight change, `act` per step."""
 
-    def __init__(self, obs_len, hidden, n_actions, n_atoms, k_pad, device, n_sets=1):
+    def __init__(self, obs_len, hidden, n_actions, n_atoms, k_pad, device, n_sets=1, dtype=torch.bfloat16):
         assert k_pad % 64 == 0 and k_pad >= obs_len and hidden % 256 == 0 and 2 <= n_atoms <= 256
+        assert dtype in (torch.bfloat16, torch.float16)
         self.obs_len, self.hidden, self.n_actions, self.n_atoms, self.k_pad = obs_len, hidden, n_actions, n_atoms, k_pad
         self.group_actions = 256 // n_atoms
         groups = -(-n_actions // self.group_actions)
-        bf = dict(dtype=torch.bfloat16, device=device)
+        bf = dict(dtype=dtype, device=device)
+        # operand type of the weights and hidden activations: bf16 (both kernel forms) or fp16 (the one-kernel form only — the
+        # reference's own network dtype; csrc/actor.hip's two-kernel form exists for bf16)
+        self.dtype, self._dt = dtype, 2 if dtype == torch.float16 else 1
+        self.two_kernel = dtype == torch.bfloat16
         # n_sets > 1: double-buffered weights (params.actor_lag): the actor reads one set while the learner packs the other
         self.n_sets = int(n_sets)
         self.sets = [(torch.zeros(hidden, k_pad, **bf), torch.zeros(hidden, dtype=torch.float32, device=device),
                       torch.zeros(groups * 256, hidden, **bf), torch.zeros(groups * 256, dtype=torch.float32, device=device))
-                     for _ in range(self.n_sets)]
-        self.w1t, self.b1, self.w2t, self.b2 = self.sets[0]
+                     for _ in range(self.n_sets)] if self.two_kernel else []
+        self.w1t, self.b1, self.w2t, self.b2 = self.sets[0] if self.two_kernel else (None, None, None, None)
         self.h = self.q = self.actions = None
         self._jobs = {}
         self._q_call = None   # q_values: cached argument addresses
@@ -102,18 +107,29 @@ class ActorMFMA:
         self._two_stale = [False] * self.n_sets   # the two-kernel form's copies of that set are behind them (lazy_two_kernel)
         # one workgroup owns 128 rows from start to end, so below ~one workgroup per two CUs the two-kernel form (more, smaller
         # workgroups) is quicker: measured 58 vs 45 us at 4 096 rows, 56 vs 48 at 7 000, equal at 16 384, 49 vs 69 at 32 768
-        self.fused_min_rows = int(os.environ.get("HB_ACTOR_FUSED_MIN_ROWS", "16385"))
+        self.fused_min_rows = int(os.environ.get("HB_ACTOR_FUSED_MIN_ROWS", "16385")) if self.two_kernel else 0
+        if not self.two_kernel and not self.fused:
+            raise ValueError("fp16 operands: only the one-kernel actor exists (hidden 512, 51 atoms)")
 
     def takes_fused(self, obs):
         """True when a policy call on `obs` runs on the one-kernel form (bit rows, enough of them)."""
         return self.fused and obs.dtype == torch.int32 and obs.shape[0] >= self.fused_min_rows and self.n_actions <= 64
+
+    def accepts(self, obs):
+        """True when this object can run a policy call on `obs` at all (else the caller's library-GEMM path takes it)."""
+        if self.two_kernel:
+            return obs.dtype in (torch.int8, torch.int32)
+        return self.takes_fused(obs)
 
     def state_tensors(self):
         """Every packed weight copy of every set (checkpoints: with actor_lag the acting set is state of its own)."""
         return [t for st in self.sets for t in st] + [t for st in self.fsets for t in st]
 
     @staticmethod
-    def supports(obs_len, hidden, n_atoms, k_pad, dtype):
+    def supports(obs_len, hidden, n_atoms, k_pad, dtype, n_actions=1):
+        if dtype == torch.float16:   # the one-kernel form only, and only where it also selects the moves
+            return (k_pad % 64 == 0 and n_actions <= 64 and os.environ.get("HB_ACTOR_FUSED", "1") != "0"
+                    and bool(K.lib().hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)))
         return dtype == torch.bfloat16 and k_pad % 64 == 0 and hidden % 256 == 0 and 2 <= n_atoms <= 256
 
     def pack(self, w1, b1, w2, b2, s=0, lazy_two_kernel=False):
@@ -124,9 +140,12 @@ class ActorMFMA:
         self._src[s] = (w1, b1, w2, b2)
         if self.fused:
             f = self._fset_ptrs[s]
-            K.check(K.lib().hb_actor_fused_pack(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
-                                                self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
-                                                K.current_stream()))
+            assert w1.dtype == self.dtype and w2.dtype == self.dtype and b1.dtype == self.dtype and b2.dtype == self.dtype
+            K.check(K.lib().hb_actor_fused_pack_dt(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+                                                   self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
+                                                   self._dt, K.current_stream()))
+        if not self.two_kernel:
+            return
         if lazy_two_kernel and self.fused:
             self._two_stale[s] = True
         else:
@@ -161,8 +180,9 @@ class ActorMFMA:
             packed = obs.dtype == torch.int32
             assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
                                             (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
-            if self.h is None or self.h.shape[0] != n:
-                self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
+            if self.q is None or self.q.shape[0] != n:
+                # (h: the hidden activations between the two kernels of the two-kernel form; a one-row stand-in without it)
+                self.h = torch.empty(n if self.two_kernel else 1, self.hidden, dtype=self.dtype, device=obs.device)
                 self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
                 self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
             L = K.lib()
@@ -172,9 +192,11 @@ class ActorMFMA:
         st = K.current_stream()
         if self.fused and obs.dtype == torch.int32 and n >= self.fused_min_rows:
             f = self._fset_ptrs[s]
-            K.check(K.lib().hb_actor_fused_q(c[0], n, self.obs_len, f[0], f[1], f[2], f[3], sp, self.hidden, self.n_actions,
-                                             self.n_atoms, qp, st))
+            K.check(K.lib().hb_actor_fused_q_dt(c[0], n, self.obs_len, f[0], f[1], f[2], f[3], sp, self.hidden, self.n_actions,
+                                                self.n_atoms, qp, self._dt, st))
             return self.q
+        if not self.two_kernel:
+            raise ValueError("fp16 operands: the one-kernel actor takes bit-packed observation rows only")
         if self._two_stale[s]:
             self._pack_two(s)
         w1p, b1p, w2p, b2p = self._set_ptrs[s]
@@ -188,19 +210,21 @@ class ActorMFMA:
         assert obs.is_contiguous() and ((packed and obs.shape[1] == (self.obs_len + 31) // 32) or
                                         (obs.dtype == torch.int8 and obs.shape[1] == self.obs_len))
         assert legal.dtype == torch.int8 and legal.is_contiguous() and legal.shape == (n, self.n_actions)
-        if self.h is None or self.h.shape[0] != n:
-            self.h = torch.empty(n, self.hidden, dtype=torch.bfloat16, device=obs.device)
+        if self.q is None or self.q.shape[0] != n:
+            self.h = torch.empty(n if self.two_kernel else 1, self.hidden, dtype=self.dtype, device=obs.device)
             self.q = torch.empty(n, self.n_actions, dtype=torch.float32, device=obs.device)
             self.tickets = torch.zeros((n + 255) // 256, dtype=torch.int32, device=obs.device)   # hb_actor_q_select
         actions = actions_out if actions_out is not None else torch.empty(n, dtype=torch.int32, device=obs.device)
         if self.fused and packed and n >= self.fused_min_rows and self.n_actions <= 64:
             # ONE launch: forward + C51 expectation + the epsilon-greedy selection on the rows each workgroup has just written
             f = self._fset_ptrs[s]
-            K.check(K.lib().hb_actor_fused_act(obs.data_ptr(), legal.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3],
-                                               support.data_ptr(), self.hidden, self.n_actions, self.n_atoms, self.q.data_ptr(),
-                                               float(epsilon), int(seed), int(draw), int(first_game_id), actions.data_ptr(),
-                                               K.current_stream()))
+            K.check(K.lib().hb_actor_fused_act_dt(obs.data_ptr(), legal.data_ptr(), n, self.obs_len, f[0], f[1], f[2], f[3],
+                                                  support.data_ptr(), self.hidden, self.n_actions, self.n_atoms, self.q.data_ptr(),
+                                                  float(epsilon), int(seed), int(draw), int(first_game_id), actions.data_ptr(),
+                                                  self._dt, K.current_stream()))
             return actions
+        if not self.two_kernel:
+            raise ValueError("fp16 operands: the one-kernel actor takes bit-packed observation rows only")
         if self._two_stale[s]:
             self._pack_two(s)
         w1p, b1p, w2p, b2p = self._set_ptrs[s]

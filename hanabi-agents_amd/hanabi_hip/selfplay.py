@@ -458,7 +458,7 @@ class _Chain:
         put(K.CMD_ACTOR_FUSED_ACT, A,
             [env.net_obs.data_ptr(), env.legal.data_ptr(), f[0], f[1], f[2], f[3], agent._support0.data_ptr(), act.q.data_ptr(),
              session._act_buf[seat].data_ptr()],
-            [env.n, act.obs_len, act.hidden, act.n_actions, act.n_atoms, agent.params.seed + 0x9E3779B9, agent.first_game_id],
+            [env.n, act.obs_len, act.hidden, act.n_actions, act.n_atoms, agent.params.seed + 0x9E3779B9, agent.first_game_id, act._dt],
             var=1, fvar=0)
         # `acted` (the policy has read its weights) is recorded BEFORE the env step unless HB_ACTED_BEFORE_ENV=0
         env_args = [env.h, session._act_buf[seat].data_ptr(), env.obs_bits.data_ptr(), None, env.legal.data_ptr(), env.reward.data_ptr(),
@@ -489,10 +489,11 @@ class _Chain:
             # (both forms of the copies), followed by that set's event
             (w1, b1), (w2, b2) = fl.eff
             put(K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]],
-                [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms])
-            jobs = next(j for kk, j in act._jobs.items() if kk[0] == wset and kk[1] == w1.data_ptr())
-            self._jobs = jobs   # (kept alive: the command holds its address)
-            put(K.CMD_ACTOR_PACK_WEIGHTS, Ls, [C.addressof(jobs)], [2])
+                [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms, act._dt])
+            if act.two_kernel:   # (fp16 operands: the one-kernel form only)
+                jobs = next(j for kk, j in act._jobs.items() if kk[0] == wset and kk[1] == w1.data_ptr())
+                self._jobs = jobs   # (kept alive: the command holds its address)
+                put(K.CMD_ACTOR_PACK_WEIGHTS, Ls, [C.addressof(jobs)], [2])
             put(K.CMD_RECORD_EVENT, Ls, [fl.packed_ev[wset].h])
         put(K.CMD_RECORD_EVENT, Ls, [agent.weights_ev.h])
         prios = agent._g_prios

@@ -370,8 +370,11 @@ int hb_replay_insert(int8_t* last_obs_dev, const int8_t* obs_dev, const int8_t* 
  *   loss mean(td * w)                                   2e-3 relative              1e-4 relative
  *   IS weights                                          1e-6 absolute              1e-6 absolute
  *   merged gradients dW1, db1, dW2, db2 (rel. L2)       0.05                       0.03
- *   actor q = mean_k softmax * atoms (|q| <= 0.49)      0.012 absolute             0.004 absolute
- *   chosen move = f32 arg-max where the f32 top-2 gap   > 0.024                    > 0.008
+ *   actor q = mean_k softmax * atoms (|q| <= 0.49)      0.012 absolute             0.003 absolute
+ *   chosen move = f32 arg-max where the f32 top-2 gap   > 0.024                    > 0.006
+ * Both types run on the same kernels at the same speed (hb_actor_fused_*_dt, hb_thin_gemm bit 2, hb_chain_run): f16 is the
+ * reference's own choice and 8 x finer; bf16 (the default) has f32's exponent range, i.e. needs no loss scaling whatever the
+ * gradients do (f16 measured: dLoss/dlogits ~ 1e-5 is subnormal there, the hidden layer's gradient loses bits: 0.02 rel. L2).
  *
  * hb_replay_gather: batch gather experience_buffer.py:83-87 straight into the GEMM operand:
  *   x_dev [2*batch, x_ld >= obs_len] (rows 0..B-1 = obs_tm1[idx], B..2B-1 = obs_t[idx]) in x_dtype,
@@ -430,7 +433,8 @@ int hb_c51_loss_sparse(const void* logits_online_dev, const void* logits_target_
  * seat's policy forward instead of queueing behind it. m % 32 == 0, n % 16 == 0, k % 32 == 0; batch >= 1 with element strides;
  * bias (bf16 [batch][n], may be NULL) and ReLU are applied before the bf16 rounding, like a library GEMM epilogue.
  * relu: bit 0 = ReLU; bit 1 = write fp32 instead of bf16 (ldo / out_batch_stride then count floats, out_dev 16-byte aligned):
- * the learner's logits are the accumulators + bias as they are (round 3), so the loss sees no bf16 rounding of the logits.    */
+ * the learner's logits are the accumulators + bias as they are (round 3), so the loss sees no bf16 rounding of the logits;
+ * bit 2 = x, wt, bias and a 16-bit output are fp16 instead of bf16 (v_mfma_f32_16x16x32_f16, the same rate).                  */
 int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
                  int32_t ldx, int32_t ldw, int32_t ldo, int32_t batch, int64_t x_batch_stride, int64_t w_batch_stride,
                  int64_t out_batch_stride, int32_t relu, void* stream);
@@ -571,6 +575,20 @@ int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, in
                        const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
                        int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
                        int64_t first_game_id, int32_t* actions_dev, void* stream);
+/* The same three with the operand type of the 16-bit weights / hidden activations as an argument: dtype 1 = bf16 (what the
+ * functions above use), 2 = fp16 — the reference's own network dtype (rlax_rainbow.py:250-251), same MFMA rate
+ * (v_mfma_f32_16x16x32_f16), 8 x finer rounding of weights and hidden activations (Precision contract above). Copies packed
+ * with one dtype must be run with the same one.                                                                               */
+int hb_actor_fused_pack_dt(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld,
+                           const void* b2_dev, int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev,
+                           float* b1f_dev, void* w2f_dev, float* b2f_dev, int32_t dtype, void* stream);
+int hb_actor_fused_q_dt(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
+                        const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
+                        int32_t n_atoms, float* q_dev, int32_t dtype, void* stream);
+int hb_actor_fused_act_dt(const uint32_t* obs_bits_dev, const int8_t* legal_dev, int64_t n_rows, int32_t obs_len,
+                          const void* w1f_dev, const float* b1f_dev, const void* w2f_dev, const float* b2f_dev,
+                          const float* support_dev, int32_t hidden, int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon,
+                          uint64_t seed, uint64_t draw, int64_t first_game_id, int32_t* actions_dev, int32_t dtype, void* stream);
 
 /* ---- One host call per step: hb_chain_run (csrc/chain.hip, round 3) ------------------------------------------------------
  * The session that drives DQNAgent (rlax_rainbow.py:277-339: explore / add_experience / update once per env step) issues ~25
@@ -581,7 +599,7 @@ int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, in
  *   var, fvar        index into vars_i / vars_f of its per-run arguments (-1: none),
  *   cond             index into vars_i of a run / skip switch (-1: always run), stream the hipStream_t it is issued on.
  * Per-run arguments: HB_CMD_REPLAY_INSERT vars_i[var] = start; HB_CMD_ACTOR_FUSED_ACT vars_i[var] = draw, vars_f[fvar] = epsilon
- * (i[5] = seed, i[6] = first_game_id); HB_CMD_TREE_FILL_RANGE vars_i[var], vars_i[var + 1] = start, n (n = 0: skipped);
+ * (i[5] = seed, i[6] = first_game_id, i[7] = operand dtype: 0 / 1 = bf16, 2 = f16; HB_CMD_ACTOR_FUSED_PACK: i[6] likewise); HB_CMD_TREE_FILL_RANGE vars_i[var], vars_i[var + 1] = start, n (n = 0: skipped);
  * HB_CMD_GRAPH_LAUNCH p[0] = a hipGraphExec_t of the caller (the captured learner update); events are hb_event_create handles.
  * Nothing is computed here: results are those of the individual calls.                                                        */
 enum {

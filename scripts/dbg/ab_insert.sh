@@ -8,7 +8,7 @@ d = json.load(open(sys.argv[2]))
 print(sys.argv[1], "ms/step", round(d["ms_per_step"], 5), "grad/s", round(d["grad_steps_per_sec"]), "host", round(d["host_enqueue_ms_per_step"], 4), "native", d.get("host_calls", {}).get("steps_through_hb_chain_run"), flush=True)
 PY
 }
-B="python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant"
+B="python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant --no-fp16-variant"
 run sync0 HB_INSERT_ON_LEARNER=0 $B
 run sync1 HB_INSERT_ON_LEARNER=1 $B
 run sync0 HB_INSERT_ON_LEARNER=0 $B

@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r03q; mkdir -p $O
 run() {
   label=$1; shift
-  env "$@" python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant > $O/skip_$label.json 2>> $O/err.log
+  env "$@" python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant --no-fp16-variant > $O/skip_$label.json 2>> $O/err.log
   python3 - "$label" $O/skip_$label.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

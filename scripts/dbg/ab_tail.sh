@@ -3,7 +3,7 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r03q; mkdir -p $O
 run() {  # label, env assignments...
   label=$1; shift
   for rep in 1 2; do
-    env "$@" python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant > $O/ab_$label.json 2>> $O/err.log
+    env "$@" python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-async-variant --no-nstep-variant --no-fp16-variant > $O/ab_$label.json 2>> $O/err.log
     python3 - "$label" $O/ab_$label.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

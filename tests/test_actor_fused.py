@@ -13,25 +13,26 @@ pytestmark = pytest.mark.gpu
 SHAPES = {"full2": (658, 20), "full3": (783, 30), "full4": (908, 38), "full5": (1280, 48), "small2": (171, 11), "one": (40, 1)}
 
 
-def _setup(obs_len, n_act, n, seed, scale2=0.2):
+def _setup(obs_len, n_act, n, seed, scale2=0.2, dtype="bfloat16"):
     import torch
 
     from hanabi_agents.rlax_dqn import bitpack
     from hanabi_hip.ops import ActorMFMA
 
+    dt = getattr(torch, dtype)
     H, K = 512, 51
     kp, np_ = (obs_len + 63) // 64 * 64, (n_act * K + 63) // 64 * 64
     g = torch.Generator(device="cuda").manual_seed(seed)
     obs = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.35).to(torch.int8)
-    w1 = torch.zeros(kp, H, device="cuda", dtype=torch.bfloat16)
-    w1[:obs_len] = (torch.randn(obs_len, H, device="cuda", generator=g) * 0.04).to(torch.bfloat16)
-    b1 = (torch.randn(H, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
-    w2 = torch.zeros(H, np_, device="cuda", dtype=torch.bfloat16)
-    w2[:, :n_act * K] = (torch.randn(H, n_act * K, device="cuda", generator=g) * scale2).to(torch.bfloat16)
-    b2 = torch.zeros(np_, device="cuda", dtype=torch.bfloat16)
-    b2[:n_act * K] = (torch.randn(n_act * K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w1 = torch.zeros(kp, H, device="cuda", dtype=dt)
+    w1[:obs_len] = (torch.randn(obs_len, H, device="cuda", generator=g) * 0.04).to(dt)
+    b1 = (torch.randn(H, device="cuda", generator=g) * 0.05).to(dt)
+    w2 = torch.zeros(H, np_, device="cuda", dtype=dt)
+    w2[:, :n_act * K] = (torch.randn(H, n_act * K, device="cuda", generator=g) * scale2).to(dt)
+    b2 = torch.zeros(np_, device="cuda", dtype=dt)
+    b2[:n_act * K] = (torch.randn(n_act * K, device="cuda", generator=g) * 0.5).to(dt)
     support = torch.linspace(-25, 25, K, device="cuda")
-    act = ActorMFMA(obs_len, H, n_act, K, kp, "cuda")
+    act = ActorMFMA(obs_len, H, n_act, K, kp, "cuda", dtype=dt)
     assert act.fused, "the fused kernel must cover this shape"
     act.fused_min_rows = 0
     act.pack(w1, b1, w2, b2)
@@ -42,21 +43,25 @@ def _reference_q(obs, w, support, obs_len, n_act):
     import torch
 
     w1, b1, w2, b2 = w
-    h = torch.relu(obs.float() @ w1[:obs_len].float() + b1.float()).to(torch.bfloat16).float()
+    h = torch.relu(obs.float() @ w1[:obs_len].float() + b1.float()).to(w1.dtype).float()
     lg = (h @ w2[:, :n_act * 51].float() + b2[:n_act * 51].float()).view(obs.shape[0], n_act, 51)
     return (torch.softmax(lg, -1) * support).sum(-1) / 51
 
 
-@pytest.mark.parametrize("shape,n", [("full2", 32768), ("full2", 1000), ("full3", 777), ("full4", 515), ("full5", 4096 + 37), ("small2", 130),
-                                     ("one", 1), ("full2", 127), ("full2", 129)])
-def test_fused_q_equals_fp32_forward(shape, n):
-    """q from the fused kernel vs the fp32 forward of the same bf16 weights. The kernel's logits are fp32 accumulators (never
-    rounded); what is left is the summation order inside a row of H, which flips a bf16 rounding of H now and then: max |dq|
-    1e-3 on |q| <= 0.49 (measured 7e-7 .. 3e-4), and the same arg-max wherever the top-2 gap exceeds 2e-3."""
+@pytest.mark.parametrize("shape,n,dtype", [("full2", 32768, "bfloat16"), ("full2", 1000, "bfloat16"), ("full3", 777, "bfloat16"),
+                                           ("full4", 515, "bfloat16"), ("full5", 4096 + 37, "bfloat16"), ("small2", 130, "bfloat16"),
+                                           ("one", 1, "bfloat16"), ("full2", 127, "bfloat16"), ("full2", 129, "bfloat16"),
+                                           ("full2", 32768, "float16"), ("full5", 4096 + 37, "float16"), ("small2", 130, "float16"),
+                                           ("full2", 129, "float16")])
+def test_fused_q_equals_fp32_forward(shape, n, dtype):
+    """q from the fused kernel vs the fp32 forward of the same bf16 (fp16: hb_actor_fused_*_dt, the reference's own network dtype)
+    weights. The kernel's logits are fp32 accumulators (never rounded); what is left is the summation order inside a row of H,
+    which flips a rounding of H now and then: max |dq| 1e-3 on |q| <= 0.49 (measured 7e-7 .. 3e-4), and the same arg-max
+    wherever the top-2 gap exceeds 2e-3."""
     import torch
 
     obs_len, n_act = SHAPES[shape]
-    act, obs, bits, w, support = _setup(obs_len, n_act, n, seed=n + n_act)
+    act, obs, bits, w, support = _setup(obs_len, n_act, n, seed=n + n_act, dtype=dtype)
     q = act.q_values(bits, support).clone()
     torch.cuda.synchronize()
     ref = _reference_q(obs, w, support, obs_len, n_act)
@@ -96,8 +101,9 @@ def test_fused_equals_two_kernel_form_and_selects_legal_moves():
         assert torch.equal(masked.gather(1, a.long()[:, None])[:, 0], masked.max(1).values)
 
 
-@pytest.mark.parametrize("shape,n", [("full2", 32768), ("full5", 900), ("small2", 130)])
-def test_fused_act_selects_like_hb_policy_select(shape, n):
+@pytest.mark.parametrize("shape,n,dtype", [("full2", 32768, "bfloat16"), ("full5", 900, "bfloat16"), ("small2", 130, "bfloat16"),
+                                           ("full2", 4099, "float16")])
+def test_fused_act_selects_like_hb_policy_select(shape, n, dtype):
     """hb_actor_fused_act (selection inside the kernel, on the q rows the workgroup has just written) == hb_actor_fused_q followed
     by hb_policy_select: identical q, identical actions (same Philox draws, same tie rule), greedy and with exploration."""
     import torch
@@ -105,7 +111,7 @@ def test_fused_act_selects_like_hb_policy_select(shape, n):
     from hanabi_hip import _capi as K
 
     obs_len, n_act = SHAPES[shape]
-    act, obs, bits, w, support = _setup(obs_len, n_act, n, seed=n)
+    act, obs, bits, w, support = _setup(obs_len, n_act, n, seed=n, dtype=dtype)
     g = torch.Generator(device="cuda").manual_seed(n + 1)
     for rep, eps in enumerate((0.0, 0.3, 1.0)):
         legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.5).to(torch.int8)
@@ -136,15 +142,16 @@ def _logit_of_column(col, n_actions, n_pass):
     return action * 51 + atom if (action < n_actions and atom < 51) else -1
 
 
-@pytest.mark.parametrize("shape", ["full2", "full3", "full5", "small2"])
-def test_pack_is_a_permutation_of_the_logit_columns(shape):
+@pytest.mark.parametrize("shape,dtype", [("full2", "bfloat16"), ("full3", "bfloat16"), ("full5", "bfloat16"), ("small2", "bfloat16"),
+                                         ("full2", "float16")])
+def test_pack_is_a_permutation_of_the_logit_columns(shape, dtype):
     """Every logit column of W2 / b2 lands in exactly one physical column of the fragment-major copy, unused columns are zero
     weights with a -1e30 bias, and W1 is the k-major fragment image of the (zero-padded) first layer."""
     import numpy as np
     import torch
 
     obs_len, n_act = SHAPES[shape]
-    act, _, _, (w1, b1, w2, b2), _ = _setup(obs_len, n_act, 8, seed=3)
+    act, _, _, (w1, b1, w2, b2), _ = _setup(obs_len, n_act, 8, seed=3, dtype=dtype)
     n_pass = (n_act + 9) // 10
     w1f, b1f, w2f, b2f = (t.cpu() for t in act.fsets[0])
     cols = np.array([_logit_of_column(c, n_act, n_pass) for c in range(512 * n_pass)])

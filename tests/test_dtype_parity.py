@@ -156,11 +156,11 @@ def test_fused_learner_reduced_precision_vs_fp32_autograd(dtype, players):
 
 
 @pytest.mark.parametrize("players", [2, 5])
-@pytest.mark.parametrize("dtype,form", [("bfloat16", "bits"), ("bfloat16", "int8"), ("float16", "int8")])
+@pytest.mark.parametrize("dtype,form", [("bfloat16", "bits"), ("bfloat16", "int8"), ("float16", "bits"), ("float16", "int8")])
 def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, form, players):
-    """bf16, bit rows: hb_actor_fused_q (csrc/actor_fused.hip, the benched form). bf16, int8 rows: hb_actor_hidden + hb_actor_q
-    (csrc/actor.hip). fp16: hb_obs_cast + library GEMMs + hb_policy_act (the fallback `_act_fused` takes for dtypes the MFMA
-    kernels do not cover). All against DQNPolicy.q_values in fp32."""
+    """Bit rows: hb_actor_fused_act[_dt] (csrc/actor_fused.hip, the benched form; bf16 and — the reference's own network dtype —
+    fp16 operands). bf16, int8 rows: hb_actor_hidden + hb_actor_q (csrc/actor.hip). fp16, int8 rows: hb_obs_cast + library GEMMs +
+    hb_policy_act (the fallback `_act_fused` takes for what the MFMA kernels do not cover). All against DQNPolicy.q_values in fp32."""
     import torch
 
     from hanabi_agents.rlax_dqn import DQNPolicy, bitpack
@@ -184,12 +184,14 @@ def test_actor_q_values_reduced_precision_vs_fp32_policy(dtype, form, players):
     if form == "bits":
         assert fl.actor is not None and fl.actor.fused, "the fused actor kernel must cover the benched shape"
         fl.actor.fused_min_rows = 0
-    act = fused._act_fused(bitpack.pack(obs) if form == "bits" else obs, legal, 0.0)
-    if dtype == "bfloat16":
-        assert fl.actor is not None, "the MFMA actor must cover the benched shape"
+    arg = bitpack.pack(obs) if form == "bits" else obs
+    act = fused._act_fused(arg, legal, 0.0)
+    assert fl.actor is not None, "the MFMA actor must cover the benched shape"
+    if dtype == "bfloat16" or form == "bits":
+        assert fl.actor.accepts(arg) and fl.actor.two_kernel == (dtype == "bfloat16")
         q_lp = fl.actor.q.clone()
     else:
-        assert fl.actor is None
+        assert not fl.actor.accepts(arg)
         (w1, b1), (w2, b2) = fl.eff
         x = torch.zeros(n, fl.Kp, dtype=fl.cd, device="cuda")
         ops.obs_cast(obs, fl.cd, out=x)

@@ -166,12 +166,13 @@ def test_selection_fused_into_the_env_step_gives_identical_training(lag):
         assert torch.equal(x, y), f"item {k} differs"
 
 
-@pytest.mark.parametrize("lag", [0, 1])
-def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
+@pytest.mark.parametrize("lag,dtype", [(0, "bfloat16"), (1, "bfloat16"), (0, "float16"), (1, "float16")])
+def test_benched_wiring_matches_oracle_replay(lag, dtype, monkeypatch):
     """The configuration bench.py times — Hanabi-Full 2 players, bit-packed observation rows end to end, [512] net in bf16 on the
     one-kernel actor (selection inside the kernel), split update on per-agent learner streams, HIP graphs, one host call per step
     (hb_chain_run) — replayed move by move on the CPU oracle: every transition that reached the two replay rings equals the
-    oracle's (observations, legal masks, per-seat rewards, terminals), synchronous actor and actor_lag = 1."""
+    oracle's (observations, legal masks, per-seat rewards, terminals), synchronous actor and actor_lag = 1 (VERDICT r2 item 6);
+    the same with fp16 operands (bench.py --compute-dtype float16: the reference's own network dtype on the same kernels)."""
     import torch
 
     import hanabi_hip
@@ -185,7 +186,7 @@ def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
     env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=n, seed=3, packed=True)
     orc = O.OracleEnv(O.make_config("Hanabi-Full", 2, flags), n, seed=3)
     params = RlaxRainbowParams(train_batch_size=256, experience_buffer_size=n * 16, layers=[512], mask_terminal=True,
-                               compute_dtype="bfloat16", packed_obs=True, actor_lag=lag, target_update_period=5)
+                               compute_dtype=dtype, packed_obs=True, actor_lag=lag, target_update_period=5)
     agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
               for s in (1, 2)]
     sess = SelfPlaySession(env, agents)      # default options: what bench.py runs
@@ -223,8 +224,8 @@ def test_benched_wiring_matches_oracle_replay(lag, monkeypatch):
             assert np.array_equal(tr.legal_moves_t[sl], lg) and np.array_equal(tr.terminal_t[sl, 0], term)
 
 
-@pytest.mark.parametrize("lag", [0, 1])
-def test_one_host_call_per_step_gives_identical_training(lag, monkeypatch):
+@pytest.mark.parametrize("lag,dtype", [(0, "bfloat16"), (1, "bfloat16"), (0, "float16")])
+def test_one_host_call_per_step_gives_identical_training(lag, dtype, monkeypatch):
     """SelfPlaySession(native_chain=True): the step replayed from an hb_cmd array by ONE hb_chain_run call (csrc/chain.hip) against
     the ordinary path's ~25 host calls: same moves every step, identical weights, moments, replay rings, sum trees and env rows."""
     import torch
@@ -240,7 +241,7 @@ def test_one_host_call_per_step_gives_identical_training(lag, monkeypatch):
         flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
         env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Full", 2, flags), n_games=1024, seed=5, packed=True)
         params = RlaxRainbowParams(train_batch_size=128, experience_buffer_size=1024 * 8, mask_terminal=True, target_update_period=6,
-                                   compute_dtype="bfloat16", packed_obs=True, layers=[512], learning_rate=0.01, n_step=n_step,
+                                   compute_dtype=dtype, packed_obs=True, layers=[512], learning_rate=0.01, n_step=n_step,
                                    actor_lag=lag)
         agents = [DQNAgent(ObservationSpec((1024, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
                   for s in (1, 2)]
