@@ -187,6 +187,12 @@ class FusedLearner:
         if not self.lag:
             # part2() has already re-packed the actor's copies behind Adam, on the stream (and inside the graph) the update ran on
             self.actor_stale = self.actor is not None and not self._packed_in_part2
+            if self._packed_in_part2 and self.actor.fused and self.actor.two_kernel:
+                # part2() packed the one-kernel form's copies and left the two-kernel form's to the next policy call that takes
+                # that form (pack(lazy_two_kernel=True)). The mark it set is a host-side effect: a REPLAYED graph does not repeat
+                # it, so it is renewed here, after every optimizer step (without this the two-kernel form — batches below
+                # fused_min_rows — kept acting on the weights of the update that was captured)
+                self.actor._two_stale[0] = True
             return
         self.pack_actor()
         s = self.n_packed % 2

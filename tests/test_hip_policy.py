@@ -154,6 +154,44 @@ def test_graphed_update_equals_eager_update():
     assert torch.allclose(agents[0].last_loss, agents[1].last_loss, rtol=1e-4)
 
 
+def test_two_kernel_actor_follows_graph_replayed_updates():
+    """bf16, a batch below ActorMFMA.fused_min_rows (the two-kernel actor form) and the update replayed from its HIP graph: the
+    policy must act on the weights of the LAST update. (The two-kernel form's weight copies are refreshed lazily, by a mark the
+    captured pack sets on the host — which a replayed graph does not repeat: FusedLearner.weights_updated renews it. Round 3
+    regression: without that the form kept acting on the weights of the captured update and a 4 096-game run learned nothing.)"""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams, bitpack
+
+    n, obs_len, n_act = 256, 658, 20
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=256, experience_buffer_size=256, target_update_period=50,
+                               compute_dtype="bfloat16", learning_rate=0.02, packed_obs=True)
+    a = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=True)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    o2 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
+    act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+    rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
+    b1, b2 = bitpack.pack(o1), bitpack.pack(o2)
+    a.add_experience_first((None, (b1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+    a.add_experience((None, (b2, legal)), act, rew, torch.ones(n, dtype=torch.int8, device="cuda"))
+    fl = a._fused_learner()
+    assert fl.actor is not None and fl.actor.fused and fl.actor.two_kernel and not fl.actor.takes_fused(b1)
+    for _ in range(8):           # the first ones capture, the rest replay
+        a.update()
+        a.exploit((None, (b1, legal)))    # a policy call between updates, as in self-play (it consumes the lazy mark)
+    assert a._graph1 is not None
+    a.exploit((None, (b1, legal)))
+    q_two = fl.actor.q.clone()            # the two-kernel form's q values of the call just made
+    fl.actor.fused_min_rows = 0           # the one-kernel form on the same weights (its copies are packed inside the graph)
+    q_one = fl.actor.q_values(b1, a.atoms[0].contiguous()).clone()
+    torch.cuda.synchronize()
+    assert float((q_two - q_one).abs().max()) <= 2e-3, float((q_two - q_one).abs().max())
+    w1_now = fl.eff[0][0][:obs_len].float()
+    assert float((w1_now - a.online.layers[0].effective()[0].float()).abs().max()) < 1e-2   # (eff follows the optimizer)
+
+
 def test_graph_warm_up_rolls_back_the_uniform_replay_generator():
     """Uniform replay (vanilla DQN, BASELINE config 2) draws its batch indices from the buffer's own generator. The graph
     capture's three warm-up updates consume draws; they are rolled back together with the weights, so after every
