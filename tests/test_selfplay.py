@@ -267,3 +267,31 @@ def test_one_host_call_per_step_gives_identical_training(lag, dtype, monkeypatch
             assert torch.equal(x, y), f"n_step {n_step}: actions differ at step {k}"
         for k, (x, y) in enumerate(zip(out_a, out_b)):
             assert torch.equal(x, y), f"n_step {n_step}: item {k} differs"
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_self_play_learns_hanabi_small(dtype):
+    """End to end, everything on the GPU (scripts/train_small.py in short): two agents in self-play on 2-player Hanabi-Small, 2 048
+    games, 4 updates per step through the HIP graphs — the mean episode score over the last 500 of 4 000 steps rises from 0.0
+    (random play bombs out) to ~3.5 (measured: bf16 3.51, fp16 3.4); required > 2. Not a parity claim: a wiring check that the
+    policy acts on what the learner learns (bf16 at this batch size takes the two-kernel actor form, whose weight copies once went
+    stale under graph replay: DESIGN section 8; fp16 takes the one-kernel form)."""
+    import hanabi_hip
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+    from hanabi_hip.selfplay import SelfPlaySession
+
+    n = 2048
+    flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
+    env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config("Hanabi-Small", 2, flags), n_games=n, seed=1, packed=True)
+    params = RlaxRainbowParams(compute_dtype=dtype, mask_terminal=True, experience_buffer_size=2 ** 18, learning_rate=2.5e-4,
+                               epsilon=lambda ts: max(0.02, 1.0 - ts / 3000.0), target_update_period=200, atom_vmax=10, packed_obs=True)
+    agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda")
+              for s in (1, 2)]
+    sess = SelfPlaySession(env, agents, updates_per_step=4)
+    sess.run(3500)
+    ep0, sc0 = env.stats()
+    sess.run(500)
+    ep1, sc1 = env.stats()
+    assert agents[0]._graph1 is not None
+    mean = (sc1 - sc0) / max(1, ep1 - ep0)
+    assert mean > 2.0, mean
