@@ -649,7 +649,7 @@ def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_ste
     for _ in range(args.prime + args.warmup):
         session.step()
     session.flush()
-    g0 = session.grad_steps
+    g0, native0 = session.grad_steps, session.native_steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -675,7 +675,7 @@ def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_ste
         from hanabi_agents.rlax_dqn.tolerance import TOLERANCE
 
         out["compute_dtype"] = dtype
-        out["host_calls"] = {"steps_through_hb_chain_run": session.native_steps}
+        out["host_calls"] = {"steps_through_hb_chain_run": session.native_steps - native0, "of": args.steps}
         out["tolerance"] = {k: TOLERANCE[dtype][k] for k in ("q_abs", "argmax_gap", "td_abs", "td_rel")}
         out["note"] = ("synchronous agent, the headline's protocol with fp16 GEMM operands (weights and hidden activations; fp32 "
                        "accumulation, master weights, softmax and loss as before): the reference's own network dtype")
