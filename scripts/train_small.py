@@ -12,12 +12,13 @@ ups = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 flags = hanabi_hip.FLAG_AUTO_RESET | hanabi_hip.FLAG_RESET_START_NEXT
 lag = int(os.environ.get("HB_ACTOR_LAG", "0"))   # 1: asynchronous actor (RlaxRainbowParams.actor_lag)
 packed = bool(int(os.environ.get("HB_PACKED", "1")))
-env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config(game, 2, flags), n_games=n, seed=int(os.environ.get("HB_SEED", "1")), packed=packed)
+players = int(os.environ.get("HB_PLAYERS", "2"))
+env = hanabi_hip.HanabiEnv(config=hanabi_hip.make_config(game, players, flags), n_games=n, seed=int(os.environ.get("HB_SEED", "1")), packed=packed)
 params = RlaxRainbowParams(compute_dtype=os.environ.get("HB_DTYPE", "bfloat16"),   # (float16: the reference's own network dtype)
                            mask_terminal=True, experience_buffer_size=2**18, learning_rate=2.5e-4,
                            epsilon=lambda ts: max(0.02, 1.0 - ts / 3000.0), target_update_period=200, atom_vmax=10,
                            packed_obs=packed, actor_lag=lag)
-agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda") for s in (1, 2)]
+agents = [DQNAgent(ObservationSpec((n, env.obs_len)), ActionSpec(env.num_actions), params._replace(seed=s), device="cuda") for s in range(1, players + 1)]
 sess = SelfPlaySession(env, agents, updates_per_step=ups, fuse_select=bool(int(os.environ.get('HB_FUSE_SELECT', '1'))),
                        split_update=bool(int(os.environ.get('HB_SPLIT', '1'))))
 t0 = time.time(); last = env.stats()
