@@ -549,12 +549,16 @@ struct PackArgs {
   uint4* w1f; float* b1f; uint4* w2f; float* b2f;
   int chunks1, chunks2;   // 16-byte chunks of w1f / w2f
   int f16;                // the 16-bit elements are fp16 (only the biases are converted: the weights are copied as they are)
+  // optional (hb_actor_fused_pack_thin): the k-contiguous (transposed) copies hb_thin_gemm reads, [512][w1t_ld] and
+  // [n_actions * 51][w2t_ld] — every thread already holds 8 consecutive k of one column, so they cost one more 16-byte store
+  uint16_t* w1t; int w1t_ld;
+  uint16_t* w2t; int w2t_ld;
 };
 __device__ __forceinline__ float bias_to_float(const __hip_bfloat16* b, int i, int f16) {
   return f16 ? __half2float(reinterpret_cast<const __half*>(b)[i]) : __bfloat162float(b[i]);
 }
 // physical column -> logit index (action * 51 + atom) or -1
-__device__ __forceinline__ int fused_logit(int col, int n_actions, int n_pass) {
+__host__ __device__ __forceinline__ int fused_logit(int col, int n_actions, int n_pass) {
   const int slot = col >> 6, c = col & 63, n = c >> 4, q = (c >> 2) & 3, j = c & 3;
   const int r16 = 4 * n + j;
   const int full_cap = 8 * n_pass;
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(256) void actor_fused_pack_kernel(const PackArgs a)
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (k0 + i < a.obs_len) ? a.w1[static_cast<long long>(k0 + i) * a.w1_ld + unit] : zero;
     a.w1f[id] = *reinterpret_cast<const uint4*>(v);
+    if (a.w1t) *reinterpret_cast<uint4*>(a.w1t + static_cast<size_t>(unit) * a.w1t_ld + k0) = *reinterpret_cast<const uint4*>(v);
     if (id < FH) a.b1f[id] = bias_to_float(a.b1, id, a.f16);
   } else if (id < a.chunks1 + a.chunks2) {
     const int id2 = id - a.chunks1;
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(256) void actor_fused_pack_kernel(const PackArgs a)
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = lg >= 0 ? a.w2[static_cast<long long>(k0 + i) * a.w2_ld + lg] : zero;
     a.w2f[id2] = *reinterpret_cast<const uint4*>(v);
+    if (a.w2t && lg >= 0) *reinterpret_cast<uint4*>(a.w2t + static_cast<size_t>(lg) * a.w2t_ld + k0) = *reinterpret_cast<const uint4*>(v);
     if (s == 0 && (lane >> 4) == 0) a.b2f[col] = lg >= 0 ? bias_to_float(a.b2, lg, a.f16) : NEG_BIG;
   }
 }
@@ -606,6 +612,20 @@ int hb_actor_fused_supported(int32_t obs_len, int32_t hidden, int32_t n_actions,
   return obs_len >= 1 && obs_len <= 4096 && hidden == FH && n_atoms == FK && n_actions >= 1 && n_actions <= 80 ? 1 : 0;   // (<= 32 passes)
 }
 
+int hb_actor_fused_columns(int32_t n_actions, int32_t* phys_of_logit_host) {
+  if (!phys_of_logit_host) return fail(HB_ERR_INVALID, "null argument");
+  if (n_actions < 1 || n_actions > 80) return fail(HB_ERR_INVALID, "n_actions must be 1..80");
+  const int np = passes_for(n_actions);
+  for (int j = 0; j < n_actions * FK; ++j) phys_of_logit_host[j] = -1;
+  for (int col = 0; col < 512 * np; ++col) {
+    const int lg = fused_logit(col, n_actions, np);
+    if (lg >= 0) phys_of_logit_host[lg] = col;
+  }
+  for (int j = 0; j < n_actions * FK; ++j)
+    if (phys_of_logit_host[j] < 0) return fail(HB_ERR_INVALID, "internal: logit column %d has no physical column", j);
+  return HB_OK;
+}
+
 int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, int64_t* w1f_bytes, int64_t* w2f_bytes,
                          int32_t* b2f_floats) {
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
@@ -619,6 +639,14 @@ int hb_actor_fused_sizes(int32_t obs_len, int32_t hidden, int32_t n_actions, int
 int hb_actor_fused_pack_dt(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld, const void* b2_dev,
                            int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev, float* b1f_dev,
                            void* w2f_dev, float* b2f_dev, int32_t dtype, void* stream) {
+  return hb_actor_fused_pack_thin(w1_dev, w1_ld, b1_dev, w2_dev, w2_ld, b2_dev, obs_len, hidden, n_actions, n_atoms, w1f_dev, b1f_dev,
+                                  w2f_dev, b2f_dev, nullptr, 0, nullptr, 0, dtype, stream);
+}
+
+int hb_actor_fused_pack_thin(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld, const void* b2_dev,
+                             int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev, float* b1f_dev,
+                             void* w2f_dev, float* b2f_dev, void* w1t_dev, int32_t w1t_ld, void* w2t_dev, int32_t w2t_ld,
+                             int32_t dtype, void* stream) {
   if (dtype != 1 && dtype != 2) return fail(HB_ERR_INVALID, "dtype must be 1 (bf16) or 2 (f16)");
   if (!w1_dev || !b1_dev || !w2_dev || !b2_dev || !w1f_dev || !b1f_dev || !w2f_dev || !b2f_dev) return fail(HB_ERR_INVALID, "null argument");
   if (!hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)) return fail(HB_ERR_INVALID, "shape not covered by the fused actor kernel");
@@ -631,6 +659,9 @@ int hb_actor_fused_pack_dt(const void* w1_dev, int32_t w1_ld, const void* b1_dev
   p.w1f = static_cast<uint4*>(w1f_dev); p.b1f = b1f_dev; p.w2f = static_cast<uint4*>(w2f_dev); p.b2f = b2f_dev;
   p.chunks1 = 32 * p.s1 * 64; p.chunks2 = 32 * p.n_pass * S2 * 64;
   p.f16 = dtype == 2 ? 1 : 0;
+  if (w1t_dev && (w1t_ld < 32 * p.s1 || w1t_ld % 8 || !aligned16(w1t_dev))) return fail(HB_ERR_INVALID, "w1t: row stride must cover the padded K (a multiple of 8), 16-byte aligned");
+  if (w2t_dev && (w2t_ld < hidden || w2t_ld % 8 || !aligned16(w2t_dev))) return fail(HB_ERR_INVALID, "w2t: row stride must cover the hidden units (a multiple of 8), 16-byte aligned");
+  p.w1t = static_cast<uint16_t*>(w1t_dev); p.w1t_ld = w1t_ld; p.w2t = static_cast<uint16_t*>(w2t_dev); p.w2t_ld = w2t_ld;
   const int blocks = (p.chunks1 + p.chunks2 + 255) / 256;
   hipLaunchKernelGGL(actor_fused_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   HB_HIP(hipGetLastError());

@@ -85,10 +85,11 @@ int hb_chain_run(const hb_cmd* cmds, int32_t count, const int64_t* vars_i, const
         break;
       case HB_CMD_ACTOR_FUSED_PACK:
         // i[6]: dtype of the 16-bit operands (0 or 1 = bf16, 2 = f16): hb_actor_fused_pack_dt
-        rc = hb_actor_fused_pack_dt(c.p[0], static_cast<int32_t>(c.i[0]), c.p[1], c.p[2], static_cast<int32_t>(c.i[1]), c.p[3],
-                                    static_cast<int32_t>(c.i[2]), static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]),
-                                    static_cast<int32_t>(c.i[5]), c.p[4], static_cast<float*>(c.p[5]), c.p[6], static_cast<float*>(c.p[7]),
-                                    c.i[6] == 2 ? 2 : 1, c.stream);
+        // p[8], i[7] / p[9], i[8]: the thin GEMMs' transposed copies and their row strides (NULL: none): hb_actor_fused_pack_thin
+        rc = hb_actor_fused_pack_thin(c.p[0], static_cast<int32_t>(c.i[0]), c.p[1], c.p[2], static_cast<int32_t>(c.i[1]), c.p[3],
+                                      static_cast<int32_t>(c.i[2]), static_cast<int32_t>(c.i[3]), static_cast<int32_t>(c.i[4]),
+                                      static_cast<int32_t>(c.i[5]), c.p[4], static_cast<float*>(c.p[5]), c.p[6], static_cast<float*>(c.p[7]),
+                                      c.p[8], static_cast<int32_t>(c.i[7]), c.p[9], static_cast<int32_t>(c.i[8]), c.i[6] == 2 ? 2 : 1, c.stream);
         break;
       case HB_CMD_ACTOR_PACK_WEIGHTS:   // p[0]: the caller's hb_pack_job array (host memory that outlives the chain), i[0]: count
         rc = hb_actor_pack_weights(static_cast<const hb_pack_job*>(c.p[0]), static_cast<int32_t>(c.i[0]), c.stream);

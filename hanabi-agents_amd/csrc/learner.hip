@@ -451,6 +451,118 @@ __global__ __launch_bounds__(256) void noisy_adam_multi_kernel(const AdamMulti m
   }
 }
 
+// ---- Adam that also writes the copies the forward kernels read (round 3) -----------------------------
+// hb_noisy_adam_multi_pack: the same optimizer step as noisy_adam_multiw_kernel<T, 4> (same arithmetic per element, same
+// row-major `eff`), and in the same pass the 16-bit copies of the new effective weights that used to take two more launches
+// per update: the k-contiguous (transposed) copy hb_thin_gemm reads (hb_actor_pack_weights before) and the fragment-major copy
+// of the one-kernel actor (hb_actor_fused_pack before), plus the fp32 biases of the latter. A workgroup owns a 32 x 32 tile
+// [k0 .. k0 + 31][n0 .. n0 + 31] of a weight tensor: thread t updates 4 consecutive columns of row t / 8 (128-byte row pieces),
+// the merged values go through a 2 KB LDS tile, and 128 threads each emit one 16-byte vector of 8 consecutive k of one column —
+// the unit both copies are made of. Bias tensors (one row) take the element-wise path and write their fp32 copy.
+struct AdamPackOut {
+  void* wt; int wt_ld;          // transposed copy [cols][wt_ld], or null
+  uint4* frag; int frag_kind;   // 0 none, 1 = W1f [s][32 nt][64 lanes], 2 = W2f [pass][16 s][32 nt][64 lanes] (csrc/actor_fused.hip)
+  const int* col_map;           // kind 2 and bias_f32 of the output layer: physical column of logit column j; null = identity
+  float* bias_f32;              // bias tensors: fp32 copy of the ROUNDED effective bias (at col_map[j] when given), or null
+};
+struct AdamPackMulti {
+  AdamArgs t[4];
+  AdamPackOut o[4];
+  int first[5];
+  int tiles_n[4];               // column tiles of a tiled (weight) tensor; 0 = element-wise (bias) tensor
+  int count;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void noisy_adam_pack_kernel(const AdamPackMulti m) {
+  __shared__ uint16_t tile[8][132];
+  int ti = 0;
+  while (ti + 1 < m.count && static_cast<int>(blockIdx.x) >= m.first[ti + 1]) ++ti;
+  const AdamArgs& a = m.t[ti];
+  const AdamPackOut& o = m.o[ti];
+  const int tid = static_cast<int>(threadIdx.x), tb = static_cast<int>(blockIdx.x) - m.first[ti];
+  const float t = *a.step + a.step_offset;
+  const float bc1 = 1.f - powf(a.b1, t), bc2s = sqrtf(1.f - powf(a.b2, t));
+  T* eff = static_cast<T*>(a.eff);
+  const int tn = m.tiles_n[ti];
+  const int rows = static_cast<int>(a.n / a.cols);
+  int k, n;                      // this thread's row and first column
+  if (tn > 0) {
+    k = (tb / tn) * 8 + (tid >> 5);
+    n = (tb % tn) * 128 + 4 * (tid & 31);
+  } else {
+    k = 0;
+    n = (tb * 256 + tid) * 4;
+  }
+  const bool valid = k < rows && n < a.cols;
+  float mv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const uint32_t i = static_cast<uint32_t>(k) * static_cast<uint32_t>(a.cols) + n;
+    float g[4], nz[4], res[3][4], lm[4], lv[4];
+    load_gradw<4>(a.grad, a.grad_dtype, static_cast<uint32_t>(k) * static_cast<uint32_t>(a.grad_ld) + n, g);
+    ldw<4>(a.noise, i, nz);
+    auto one = [&](float* p, float* mp, float* vp, int which) {
+      float pa[4], ma[4], va[4];
+      ldw<4>(p, i, pa); ldw<4>(mp, i, ma); ldw<4>(vp, i, va);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pa[j] = adam1(pa[j], which == 2 ? __fmul_rn(g[j], nz[j]) : g[j], ma[j], va[j], a.b1, a.b2, bc1, bc2s, a.lr, a.eps);
+        res[which][j] = pa[j];
+        lm[j] = ma[j];
+        lv[j] = va[j];
+      }
+      stw<4>(p, i, pa); stw<4>(mp, i, ma); stw<4>(vp, i, va);
+    };
+    one(a.w, a.m_w, a.v_w, 0);
+    if (a.m_mu == a.m_w) {
+      float pv[4];
+      ldw<4>(a.w_mu, i, pv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[1][j] = pv[j] = __fsub_rn(pv[j], adam_step(lm[j], lv[j], bc1, bc2s, a.lr, a.eps));
+      stw<4>(a.w_mu, i, pv);
+    } else {
+      one(a.w_mu, a.m_mu, a.v_mu, 1);
+    }
+    one(a.w_sigma, a.m_sg, a.v_sg, 2);
+    const uint32_t e = static_cast<uint32_t>(k) * static_cast<uint32_t>(a.eff_ld) + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = merged(res[0][j], res[1][j], res[2][j], nz[j]);
+      st<T>(eff, e + j, mv[j]);
+    }
+    if (tn == 0 && o.bias_f32) {   // the rounded value, as the packers read it back from `eff`
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.bias_f32[o.col_map ? o.col_map[n + j] : n + j] = ld<T>(eff, e + j);
+    }
+  }
+  if (tn == 0 || (!o.wt && !o.frag_kind)) return;   // (workgroup-uniform)
+  {
+    T r4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st<T>(r4, j, mv[j]);   // rows / columns past the tensor: zeros, like the packers' padding
+    *reinterpret_cast<uint2*>(&tile[tid >> 5][4 * (tid & 31)]) = *reinterpret_cast<const uint2*>(r4);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int col = tid;
+    const int nn = (tb % tn) * 128 + col, k0 = (tb / tn) * 8;
+    if (nn < a.cols) {
+      uint16_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = tile[i][col];
+      const uint4 vec = *reinterpret_cast<const uint4*>(v);
+      if (o.wt) *reinterpret_cast<uint4*>(static_cast<uint16_t*>(o.wt) + static_cast<size_t>(nn) * o.wt_ld + k0) = vec;
+      const int s = k0 >> 5, ch = (k0 >> 3) & 3;
+      if (o.frag_kind == 1) {
+        o.frag[(s * 32 + (nn >> 4)) * 64 + ch * 16 + (nn & 15)] = vec;
+      } else if (o.frag_kind == 2) {
+        const int ph = o.col_map[nn];
+        o.frag[(((ph >> 9) * 16 + s) * 32 + ((ph & 511) >> 4)) * 64 + ch * 16 + (ph & 15)] = vec;
+      }
+    }
+  }
+}
+
 template <typename T>
 void launch_adam(const AdamArgs& a, hipStream_t s) {
   long long blocks = (a.n + 255) / 256;
@@ -646,6 +758,62 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors, int32_t count, const floa
   else if (eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_multi_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
   else if (eff_dtype == 2) hipLaunchKernelGGL((noisy_adam_multi_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
   else return fail(HB_ERR_INVALID, "eff_dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  HB_HIP(hipGetLastError());
+  return HB_OK;
+}
+
+
+int hb_noisy_adam_multi_pack(const hb_adam_tensor* tensors, const hb_adam_pack* packs, int32_t count, const float* step_dev,
+                             float step_offset, int32_t eff_dtype, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!tensors || !packs || !step_dev) return fail(HB_ERR_INVALID, "null argument");
+  if (count < 1 || count > 4) return fail(HB_ERR_INVALID, "count must be 1..4");
+  if (eff_dtype != 1 && eff_dtype != 2) return fail(HB_ERR_INVALID, "eff_dtype must be 1 (bf16) or 2 (f16): the copies are 16-bit");
+  AdamPackMulti m{};
+  m.count = count;
+  int blocks = 0;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  for (int i = 0; i < count; ++i) {
+    const hb_adam_tensor& d = tensors[i];
+    const hb_adam_pack& k = packs[i];
+    if (!d.w || !d.w_mu || !d.w_sigma || !d.noise || !d.grad || !d.m_w || !d.v_w || !d.m_mu || !d.v_mu || !d.m_sigma ||
+        !d.v_sigma || !d.eff)
+      return fail(HB_ERR_INVALID, "null pointer in tensor %d", i);
+    if (d.n <= 0 || d.cols < 1 || d.eff_ld < d.cols || d.n % d.cols) return fail(HB_ERR_INVALID, "bad shape in tensor %d", i);
+    const int gl = d.grad_ld ? d.grad_ld : d.cols;
+    const long long rows = d.n / d.cols;
+    if (d.grad_dtype < 0 || d.grad_dtype > 2 || gl < d.cols) return fail(HB_ERR_INVALID, "bad gradient dtype / row stride in tensor %d", i);
+    // 16-byte accesses and 32-bit element offsets, as in the 4-wide kernel
+    if (d.cols % 4 || d.n >= (1LL << 30) || rows * static_cast<long long>(d.eff_ld > gl ? d.eff_ld : gl) >= (1LL << 31) || d.eff_ld % 4 ||
+        gl % 4 || !al16(d.w) || !al16(d.w_mu) || !al16(d.w_sigma) || !al16(d.noise) || !al16(d.grad) || !al16(d.m_w) || !al16(d.v_w) ||
+        !al16(d.m_mu) || !al16(d.v_mu) || !al16(d.m_sigma) || !al16(d.v_sigma) || (reinterpret_cast<uintptr_t>(d.eff) & 7u))
+      return fail(HB_ERR_ALIGN, "tensor %d: needs cols, row strides %% 4 == 0 and 16-byte aligned arrays", i);
+    const bool tiled = rows > 1;
+    if (tiled) {
+      if (k.bias_f32) return fail(HB_ERR_INVALID, "tensor %d: bias_f32 is for one-row (bias) tensors", i);
+      if (k.frag_kind < 0 || k.frag_kind > 2 || (k.frag_kind != 0) != (k.frag != nullptr)) return fail(HB_ERR_INVALID, "tensor %d: frag / frag_kind", i);
+      if (k.frag_kind == 2 && (!k.col_map_dev || rows % 32)) return fail(HB_ERR_INVALID, "tensor %d: the output layer's copy needs col_map and rows %% 32 == 0", i);
+      if (k.frag_kind == 1 && d.cols != 512) return fail(HB_ERR_INVALID, "tensor %d: the first layer's fragment copy is for 512 hidden units", i);
+      if (k.wt && (k.wt_ld < (rows + 7) / 8 * 8 || k.wt_ld % 8 || !al16(k.wt))) return fail(HB_ERR_INVALID, "tensor %d: wt_ld must cover the rows rounded up to 8 (and be a multiple of 8), wt 16-byte aligned", i);
+      if (k.frag && !al16(k.frag)) return fail(HB_ERR_ALIGN, "tensor %d: frag must be 16-byte aligned", i);
+    } else if (k.wt || k.frag || k.frag_kind) {
+      return fail(HB_ERR_INVALID, "tensor %d: a one-row tensor has no transposed / fragment copy", i);
+    }
+    m.t[i] = AdamArgs{d.w, d.w_mu, d.w_sigma, d.noise, d.grad, d.m_w, d.v_w, d.m_mu, d.v_mu, d.m_sigma, d.v_sigma,
+                      step_dev, d.eff, d.n, d.cols, d.eff_ld, d.grad_dtype, gl, lr, beta1, beta2, eps, step_offset};
+    m.o[i] = AdamPackOut{k.wt, k.wt_ld, static_cast<uint4*>(k.frag), k.frag_kind, k.col_map_dev, k.bias_f32};
+    m.first[i] = blocks;
+    if (tiled) {
+      m.tiles_n[i] = (d.cols + 127) / 128;
+      blocks += static_cast<int>((rows + 7) / 8) * m.tiles_n[i];
+    } else {
+      m.tiles_n[i] = 0;
+      blocks += static_cast<int>((d.n / 4 + 255) / 256);
+    }
+  }
+  m.first[count] = blocks;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eff_dtype == 1) hipLaunchKernelGGL((noisy_adam_pack_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, m);
+  else hipLaunchKernelGGL((noisy_adam_pack_kernel<__half>), dim3(blocks), dim3(256), 0, s, m);
   HB_HIP(hipGetLastError());
   return HB_OK;
 }

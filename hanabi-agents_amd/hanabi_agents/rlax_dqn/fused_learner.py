@@ -134,9 +134,20 @@ class FusedLearner:
         self.packed_ev = [None, None]
         if ActorMFMA.supports(self.L, H, self.Kk, self.Kp, self.cd, self.A) and getattr(agent, "use_mfma_actor", True):
             self.actor = ActorMFMA(self.L, H, self.A, self.Kk, self.Kp, dev, n_sets=2 if self.lag else 1, dtype=self.cd)
+        # one pack launch per update: hb_actor_fused_pack_thin writes the thin GEMMs' transposed ONLINE weights together with the
+        # one-kernel actor's copies, right behind Adam; part1() then launches no transposer (HB_PACK_THIN=0: two launches as before)
+        self.pack_thin = bool(self.thin and self.actor is not None and self.actor.fused and os.environ.get("HB_PACK_THIN", "1") != "0")
         if self.lag and (self.actor is None or not agent.params.use_priority or agent.params.resample_noise):
             raise ValueError("actor_lag=1 needs the MFMA actor (bf16 GEMM dtype, one hidden layer of a multiple of 256 units), "
                              "prioritized replay and frozen noise")
+        # Round 3, measured and NOT the default: Adam itself writing the copies the forward kernels read
+        # (hb_noisy_adam_multi_pack: the thin GEMMs' transposed online weights and the one-kernel actor's fragment-major set 0) — two
+        # launches fewer per update, but the kernel must walk the tensors in 8 x 128 tiles to own 8 consecutive k of a column, and
+        # its eleven 55 MB streams then run in 512-byte pieces: 27 us against 12.5 (Adam) + 5.5 + 4.5 (the two packers); the step
+        # time is the same (profiles/r03/ab_update_tail.txt). HB_ADAM_PACK=1 selects it. What IS the default: the one-kernel
+        # actor's packer also writes the thin GEMMs' copies (one launch instead of two, `pack_thin`).
+        self.adam_pack = None
+        self._pack_tab = None
         self._gw2_out = torch.zeros(H, self.Np, dtype=self.cd, device=dev)
         self._gw1_out = torch.zeros(self.Kp, H, dtype=self.cd, device=dev)
         self.refresh_effective()
@@ -182,6 +193,10 @@ class FusedLearner:
             self.actor_stale = False
             self.packed_ev = [None, None]
 
+    def _thin_out(self):
+        """The thin GEMMs' transposed online weights as extra outputs of the actor's pack launch (pack_thin), else None."""
+        return (self.w1catT, self.Kp, self.w2stT[0], self.H) if self.pack_thin else None
+
     def weights_updated(self):
         """Called after every optimizer step, on the stream the step ran on."""
         if not self.lag:
@@ -197,7 +212,7 @@ class FusedLearner:
         self.pack_actor()
         s = self.n_packed % 2
         (w1, b1), (w2, b2) = self.eff
-        self.actor.pack(w1, b1, w2, b2, s)
+        self.actor.pack(w1, b1, w2, b2, s, thin=self._thin_out())
         if self.packed_ev[s] is None:
             self.packed_ev[s] = K.Event()
         self.packed_ev[s].record()
@@ -253,6 +268,9 @@ class FusedLearner:
         buf, B = a.experience, self.B
         if self.direct is None:
             self.direct = not a._collective()
+        if self.adam_pack is None:
+            self.adam_pack = bool(self.direct and self.thin and not self.lag and self.actor is not None and self.actor.fused
+                                  and self.H == 512 and os.environ.get("HB_ADAM_PACK", "0") == "1")
         if a.params.n_step > 1 and (buf.rows_per_insert is None or buf.rows_per_insert < 1):
             raise ValueError("n_step > 1 needs inserts of a constant row count (lock-step self-play)")
         s = K.current_stream()
@@ -269,7 +287,8 @@ class FusedLearner:
             hcat, logits = self._hcat, self._logits
             # the transposed online weights are refreshed HERE (not right after Adam): the acting stream does not wait for
             # it, and like the two GEMMs below the small transposer runs beside the other seat's policy GEMMs
-            self._transpose(0)
+            if not (self.adam_pack or self.pack_thin):   # (else the pack behind Adam keeps the online half current)
+                self._transpose(0)
             f16 = 4 if self.cd == torch.float16 else 0   # (hb_thin_gemm: bit 2 of its flags = fp16 operands)
             K.check(L.hb_thin_gemm(K.dptr(self.x), K.dptr(self.w1catT), K.dptr(self.b1cat), K.dptr(hcat), 2 * B, 2 * H, self.Kp,
                                    self.Kp, self.Kp, 2 * H, 1, 0, 0, 0, 1 | f16, s))                 # bias + ReLU, [2B, 2H]
@@ -342,8 +361,33 @@ class FusedLearner:
             self._adam_tab = tab
         return self._adam_tab
 
+    def _pack_table(self):
+        """hb_adam_pack entries for the four merged tensors (order of _adam_table: W1, b1, W2, b2), built once."""
+        if self._pack_tab is None:
+            import ctypes
+
+            n_log = self.A * self.Kk
+            host = (ctypes.c_int32 * n_log)()
+            K.check(K.lib().hb_actor_fused_columns(self.A, host))
+            self._col_map = torch.tensor(list(host), dtype=torch.int32, device=self.agent.device)
+            f = self.actor.fsets[0]          # (w1f, b1f, w2f, b2f) of weight set 0
+            tab = (K.HbAdamPack * 4)()
+            tab[0].wt, tab[0].wt_ld, tab[0].frag, tab[0].frag_kind = self.w1catT.data_ptr(), self.Kp, f[0].data_ptr(), 1
+            tab[1].bias_f32 = f[1].data_ptr()
+            tab[2].wt, tab[2].wt_ld, tab[2].frag, tab[2].frag_kind = self.w2stT[0].data_ptr(), self.H, f[2].data_ptr(), 2
+            tab[2].col_map_dev = self._col_map.data_ptr()
+            tab[3].bias_f32, tab[3].col_map_dev = f[3].data_ptr(), self._col_map.data_ptr()
+            self._pack_tab = tab
+        return self._pack_tab
+
     def part2(self):
         p = self.agent.params
+        if self.adam_pack:
+            # one launch: optimizer step + the thin GEMMs' transposed online weights + the one-kernel actor's copies (set 0)
+            K.check(K.lib().hb_noisy_adam_multi_pack(self._adam_table(), self._pack_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
+                                                     float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
+            self._packed_in_part2 = True     # (the two-kernel actor form's copies: lazily, weights_updated() marks them)
+            return
         # self.step was advanced by this update's loss kernel (part1): it already is this step's number
         K.check(K.lib().hb_noisy_adam_multi(self._adam_table(), 4, K.dptr(self.step), 0.0, _DT[self.cd],
                                             float(p.learning_rate), 0.9, 0.999, 3.125e-5, K.current_stream()))
@@ -354,7 +398,7 @@ class FusedLearner:
         self._packed_in_part2 = False
         if self.actor is not None and not self.lag:
             (w1, b1), (w2, b2) = self.eff
-            self.actor.pack(w1, b1, w2, b2, 0, lazy_two_kernel=True)
+            self.actor.pack(w1, b1, w2, b2, 0, lazy_two_kernel=True, thin=self._thin_out())
             self._packed_in_part2 = True
 
     def loss(self):

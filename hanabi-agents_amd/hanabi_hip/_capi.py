@@ -44,6 +44,13 @@ class HbAdamTensor(C.Structure):
                                                                                    ("grad_dtype", C.c_int32), ("grad_ld", C.c_int32)]
 
 
+class HbAdamPack(C.Structure):
+    """`hb_adam_pack` of include/hanabi_hip.h."""
+
+    _fields_ = [("wt", C.c_void_p), ("frag", C.c_void_p), ("col_map_dev", C.c_void_p), ("bias_f32", C.c_void_p),
+                ("wt_ld", C.c_int32), ("frag_kind", C.c_int32)]
+
+
 class HbPackJob(C.Structure):
     """`hb_pack_job` of include/hanabi_hip.h."""
 
@@ -162,7 +169,10 @@ SIGNATURES = {
     "hb_actor_fused_pack": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "hb_actor_fused_q": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "hb_actor_fused_act": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_float, _U64, _U64, _I64, _P, _P]),
+    "hb_actor_fused_columns": (C.c_int, [_I32, C.POINTER(_I32)]),
+    "hb_noisy_adam_multi_pack": (C.c_int, [_P, _P, _I32, _P, C.c_float, _I32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hb_actor_fused_pack_dt": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P]),
+    "hb_actor_fused_pack_thin": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _P]),
     "hb_actor_fused_q_dt": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P]),
     "hb_actor_fused_act_dt": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_float, _U64, _U64, _I64, _P, _I32, _P]),
     "hb_chain_run": (C.c_int, [C.POINTER(HbCmd), _I32, C.POINTER(_I64), C.POINTER(_F64)]),

@@ -132,18 +132,23 @@ class ActorMFMA:
                     and bool(K.lib().hb_actor_fused_supported(obs_len, hidden, n_actions, n_atoms)))
         return dtype == torch.bfloat16 and k_pad % 64 == 0 and hidden % 256 == 0 and 2 <= n_atoms <= 256
 
-    def pack(self, w1, b1, w2, b2, s=0, lazy_two_kernel=False):
+    def pack(self, w1, b1, w2, b2, s=0, lazy_two_kernel=False, thin=None):
         """w1 [>= obs_len, hidden] and w2 [hidden, >= A*K] (bf16, possibly padded GEMM operands), b1 [hidden], b2 [>= A*K];
         s: the weight set written. One launch for the one-kernel form's fragment-major copies; the transposed copies of the
         two-kernel form in a second launch — or, with lazy_two_kernel (only sound when the sources still hold the SAME weights
-        whenever that form is next used: the synchronous agent's persistent `eff` operands), not until a policy call takes it."""
+        whenever that form is next used: the synchronous agent's persistent `eff` operands), not until a policy call takes it.
+        thin = (w1t, w1t_ld, w2t, w2t_ld): the same launch also writes the k-contiguous copies hb_thin_gemm reads (the learner's
+        forward), which otherwise take a launch of hb_actor_pack_weights of their own."""
         self._src[s] = (w1, b1, w2, b2)
         if self.fused:
             f = self._fset_ptrs[s]
             assert w1.dtype == self.dtype and w2.dtype == self.dtype and b1.dtype == self.dtype and b2.dtype == self.dtype
-            K.check(K.lib().hb_actor_fused_pack_dt(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
-                                                   self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
-                                                   self._dt, K.current_stream()))
+            t = (thin[0].data_ptr(), int(thin[1]), thin[2].data_ptr(), int(thin[3])) if thin is not None else (None, 0, None, 0)
+            K.check(K.lib().hb_actor_fused_pack_thin(w1.data_ptr(), w1.stride(0), b1.data_ptr(), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+                                                     self.obs_len, self.hidden, self.n_actions, self.n_atoms, f[0], f[1], f[2], f[3],
+                                                     t[0], t[1], t[2], t[3], self._dt, K.current_stream()))
+        elif thin is not None:
+            raise ValueError("thin copies ride on the one-kernel actor's packer")
         if not self.two_kernel:
             return
         if lazy_two_kernel and self.fused:

@@ -488,8 +488,10 @@ class _Chain:
             # FusedLearner.weights_updated(): the update's result goes into the weight set the NEXT-but-one policy call reads
             # (both forms of the copies), followed by that set's event
             (w1, b1), (w2, b2) = fl.eff
-            put(K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]],
-                [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms, act._dt])
+            th = fl._thin_out()    # (pack_thin: the thin GEMMs' transposed online weights ride on this launch)
+            put(K.CMD_ACTOR_FUSED_PACK, Ls, [w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), f[0], f[1], f[2], f[3]] +
+                ([th[0].data_ptr(), th[2].data_ptr()] if th else [0, 0]),
+                [w1.stride(0), w2.stride(0), act.obs_len, act.hidden, act.n_actions, act.n_atoms, act._dt] + ([th[1], th[3]] if th else [0, 0]))
             if act.two_kernel:   # (fp16 operands: the one-kernel form only)
                 jobs = next(j for kk, j in act._jobs.items() if kk[0] == wset and kk[1] == w1.data_ptr())
                 self._jobs = jobs   # (kept alive: the command holds its address)

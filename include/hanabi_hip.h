@@ -497,6 +497,26 @@ int hb_noisy_adam_multi(const hb_adam_tensor* tensors /* host array of device po
                         const float* step_dev, float step_offset, int32_t eff_dtype, float lr, float beta1, float beta2,
                         float eps, void* stream);
 
+/* hb_noisy_adam_multi_pack (round 3): the same step for the (up to 4) merged tensors of the one-hidden-layer network, which ALSO
+ * writes, in the same pass over the new effective weights, the copies the forward kernels read — what hb_actor_pack_weights (the
+ * k-contiguous copies of hb_thin_gemm) and hb_actor_fused_pack (the fragment-major copies of the one-kernel actor) otherwise
+ * produce in two more launches per update. eff_dtype 1 (bf16) or 2 (f16). packs[i] describes tensor i's extra outputs:
+ *   weight tensors (more than one row): wt = transposed copy [cols][wt_ld] (wt_ld >= rows rounded up to 8), or NULL;
+ *     frag + frag_kind = the one-kernel actor's copy: 1 = first layer (W1f; cols must be 512), 2 = output layer (W2f; needs
+ *     col_map_dev = hb_actor_fused_columns' physical column of every logit column), 0 / NULL = none;
+ *   bias tensors (one row): bias_f32 = fp32 copy of the ROUNDED effective bias, at col_map_dev[j] when that is given, or NULL.
+ * Same arithmetic per element as hb_noisy_adam_multi; the copies equal what the two packers make of `eff` bit for bit
+ * (tests/test_hip_policy.py).                                                                                                 */
+typedef struct hb_adam_pack {
+  void* wt;
+  void* frag;
+  const int32_t* col_map_dev;
+  float* bias_f32;
+  int32_t wt_ld, frag_kind;
+} hb_adam_pack;
+int hb_noisy_adam_multi_pack(const hb_adam_tensor* tensors, const hb_adam_pack* packs, int32_t count, const float* step_dev,
+                             float step_offset, int32_t eff_dtype, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* ReLU backward fused with the bias gradient (the `jax.grad` of relu + the bias add, rlax_rainbow.py:203-206 through
  * noisy_mlp.py:176-185): dy_dev [rows, cols] is masked in place where act_dev (the post-activation) is <= 0, and
  * out_dev[j] = sum over rows of the masked values (fp32, fixed order).                                          */
@@ -575,6 +595,9 @@ int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, in
                        const float* b1f_dev, const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden,
                        int32_t n_actions, int32_t n_atoms, float* q_dev, float epsilon, uint64_t seed, uint64_t draw,
                        int64_t first_game_id, int32_t* actions_dev, void* stream);
+/* Physical column (0 .. 512 * ceil(n_actions / 10) - 1) of every logit column action * 51 + atom in the one-kernel actor's
+ * output-layer copy / bias: n_actions * 51 ints into HOST memory (for hb_noisy_adam_multi_pack's col_map_dev: upload it).   */
+int hb_actor_fused_columns(int32_t n_actions, int32_t* phys_of_logit_host);
 /* The same three with the operand type of the 16-bit weights / hidden activations as an argument: dtype 1 = bf16 (what the
  * functions above use), 2 = fp16 — the reference's own network dtype (rlax_rainbow.py:250-251), same MFMA rate
  * (v_mfma_f32_16x16x32_f16), 8 x finer rounding of weights and hidden activations (Precision contract above). Copies packed
@@ -582,6 +605,13 @@ int hb_actor_fused_act(const uint32_t* obs_bits_dev, const int8_t* legal_dev, in
 int hb_actor_fused_pack_dt(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld,
                            const void* b2_dev, int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms, void* w1f_dev,
                            float* b1f_dev, void* w2f_dev, float* b2f_dev, int32_t dtype, void* stream);
+/* hb_actor_fused_pack_dt that ALSO writes the k-contiguous (transposed) copies hb_thin_gemm reads — w1t_dev [hidden][w1t_ld >=
+ * obs_len rounded up to 64], w2t_dev [n_actions * n_atoms][w2t_ld >= hidden], 16-bit, either may be NULL — so that an update
+ * needs ONE pack launch instead of hb_actor_pack_weights + hb_actor_fused_pack (round 3: 5.5 us and a hand-over per update).   */
+int hb_actor_fused_pack_thin(const void* w1_dev, int32_t w1_ld, const void* b1_dev, const void* w2_dev, int32_t w2_ld,
+                             const void* b2_dev, int32_t obs_len, int32_t hidden, int32_t n_actions, int32_t n_atoms,
+                             void* w1f_dev, float* b1f_dev, void* w2f_dev, float* b2f_dev, void* w1t_dev, int32_t w1t_ld,
+                             void* w2t_dev, int32_t w2t_ld, int32_t dtype, void* stream);
 int hb_actor_fused_q_dt(const uint32_t* obs_bits_dev, int64_t n_rows, int32_t obs_len, const void* w1f_dev, const float* b1f_dev,
                         const void* w2f_dev, const float* b2f_dev, const float* support_dev, int32_t hidden, int32_t n_actions,
                         int32_t n_atoms, float* q_dev, int32_t dtype, void* stream);

@@ -192,6 +192,72 @@ def test_two_kernel_actor_follows_graph_replayed_updates():
     assert float((w1_now - a.online.layers[0].effective()[0].float()).abs().max()) < 1e-2   # (eff follows the optimizer)
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("players", [2, 5])
+def test_adam_that_packs_equals_adam_plus_pack_launches(dtype, players):
+    """hb_noisy_adam_multi_pack (optimizer step + the thin GEMMs' transposed online weights + the one-kernel actor's fragment-major
+    copies and fp32 biases in ONE launch) against hb_noisy_adam_multi followed by hb_actor_pack_weights and hb_actor_fused_pack:
+    identical parameters, moments and effective weights after 4 updates, and copies that equal, bit for bit, what the two packers
+    make of the final effective weights. 2-player (658 -> 512 -> 20 x 51) and 5-player (1280 -> 512 -> 48 x 51) shapes."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams
+
+    obs_len, n_act = {2: (658, 20), 5: (1280, 48)}[players]
+    n = 256
+    params = RlaxRainbowParams(use_priority=False, train_batch_size=n, experience_buffer_size=n, target_update_period=3,
+                               compute_dtype=dtype, learning_rate=0.01)
+    agents = [DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda", use_graphs=False) for _ in (0, 1)]
+    g = torch.Generator(device="cuda").manual_seed(players)
+    o1 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    o2 = (torch.rand(n, obs_len, device="cuda", generator=g) < 0.4).to(torch.int8)
+    legal = torch.ones(n, n_act, dtype=torch.int8, device="cuda")
+    act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+    rew = torch.randint(-1, 2, (n,), device="cuda", generator=g).float()
+    for a, fused_pack in zip(agents, (True, False)):
+        a.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+        a.add_experience((None, (o2, legal)), act, rew, torch.ones(n, dtype=torch.int8, device="cuda"))
+        a.experience.sample_indices_dev = lambda b: torch.arange(b, device="cuda")
+        fl = a._fused_learner()
+        assert fl.actor is not None and fl.actor.fused and fl.thin
+        fl.pack_actor()
+        fl.adam_pack = fused_pack     # (HB_ADAM_PACK=1 in a run; the default is the separate launches: the merged kernel is slower)
+        for _ in range(4):      # (one of them is followed by a target sync)
+            a.update()
+    fa, fb = agents[0]._fl, agents[1]._fl
+    assert fa.adam_pack is True and fb.adam_pack is False
+    for pa, pb in zip(agents[0].online.parameters(), agents[1].online.parameters()):
+        assert torch.equal(pa, pb)
+    for ka in fa.state:
+        assert torch.equal(fa.state[ka][0], fb.state[ka][0]) and torch.equal(fa.state[ka][1], fb.state[ka][1])
+    for (wa, ba), (wb, bb) in zip(fa.eff, fb.eff):
+        assert torch.equal(wa, wb) and torch.equal(ba, bb)
+    # the copies Adam wrote == the packers' output for the same effective weights
+    got = [fa.w1catT.clone(), fa.w2stT.clone()] + [t.clone() for t in fa.actor.fsets[0]]
+    fa._transpose(0)
+    (w1, b1), (w2, b2) = fa.eff
+    fa.actor.pack(w1, b1, w2, b2, 0, lazy_two_kernel=True)
+    want = [fa.w1catT, fa.w2stT] + list(fa.actor.fsets[0])
+    for k, (x, y) in enumerate(zip(got, want)):
+        assert torch.equal(x, y), f"copy {k} differs: {(x != y).sum().item()} elements"
+    # one pack launch (hb_actor_fused_pack_thin: the thin GEMMs' transposed copies as extra outputs of the one-kernel actor's packer,
+    # what every update runs by default) == the two launches
+    want_t = [fa.w1catT.clone(), fa.w2stT.clone()]
+    fa.w1catT[:fa.H].zero_()
+    fa.w2stT[0].zero_()
+    assert fa.pack_thin and fb.pack_thin
+    fa.actor.pack(w1, b1, w2, b2, 0, lazy_two_kernel=True, thin=fa._thin_out())
+    assert torch.equal(fa.w1catT, want_t[0]) and torch.equal(fa.w2stT, want_t[1])
+    for x, y in zip(fa.actor.fsets[0], want[2:]):
+        assert torch.equal(x, y)
+    assert torch.equal(fb.w1catT, fa.w1catT) and torch.equal(fb.w2stT, fa.w2stT)   # (the other agent's, written during its updates)
+    # and the unfused agent's copies, made by the packers during its updates, are the same
+    fb.pack_actor()
+    if fb.actor_stale is False and fb._packed_in_part2:
+        for x, y in zip(fa.actor.fsets[0], fb.actor.fsets[0]):
+            assert torch.equal(x, y)
+
+
 def test_graph_warm_up_rolls_back_the_uniform_replay_generator():
     """Uniform replay (vanilla DQN, BASELINE config 2) draws its batch indices from the buffer's own generator. The graph
     capture's three warm-up updates consume draws; they are rolled back together with the weights, so after every
@@ -310,7 +376,11 @@ def test_batched_gpu_loss_equals_reference_loss_and_gradient():
         assert torch.allclose(loss_a, loss_b, rtol=1e-5)
         assert torch.allclose(td_a, td_b, rtol=1e-4, atol=1e-5)
         for ga, gb in zip(grads_a, grads_b):
-            assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-7 + 2e-4 * float(gb.abs().max()))  # fp32 GEMMs of different M: summation order
+            # fp32 GEMMs of different M (and whatever algorithm hipBLASLt picks on the box): the summation order differs. Measured
+            # against the tensor's scale, not element by element (an element near zero has no relative error to speak of)
+            scale = float(gb.abs().max())
+            assert float((ga - gb).abs().max()) <= 1e-7 + 1e-3 * scale, (float((ga - gb).abs().max()), scale)
+            assert float((ga.double() - gb.double()).norm() / gb.double().norm()) < 1e-4
 
 
 @pytest.mark.parametrize("mask,priority,n_step", [(False, False, 1), (True, False, 1), (True, True, 1), (True, False, 3)])
