@@ -281,11 +281,49 @@ class DQNAgent:
         if pa is None:
             pa = self._plain_actor = ActorMFMA(self.obs_len, hidden, self.n_actions, 2, kp, self.device)   # (only its hidden half is used)
             pa.stale = True
+            pa.graph = pa.graph_seen = None
         fv = self._fv
+        if (fv is not None and fv.cd == torch.bfloat16 and self._graphs_enabled() and obs.is_contiguous()
+                and os.environ.get("HB_PLAIN_ACT_GRAPH", "1") != "0"):
+            # Config 2 is host-bound (4 096 games: ~0.17 ms of Python per step for ~0.1 ms of GPU work): the weight refresh (one
+            # transposer launch + two strided copies from the learner's persistent bf16 operands), the hidden-layer kernel, the
+            # cast and the tiny output GEMM are replayed as ONE HIP graph once the same observation buffer has been seen three
+            # times (lock-step self-play passes the env's persistent rows); only the selection, whose draw counter and epsilon
+            # change per call, stays a launch of its own. Same kernels, same operands: identical q values and moves.
+            key = (obs.data_ptr(), obs.shape[0], obs.dtype, id(fv), fv.w1cat.data_ptr())
+            pg = getattr(pa, "graph", None)
+            if pg is not None and pg[0] == key:
+                pg[1].replay()
+                pa.stale, self._eff_cache = False, True
+                return self._plain_select(pg[2], legal, epsilon, obs.shape[0])
+            seen = getattr(pa, "graph_seen", None)
+            pa.graph_seen = (key, seen[1] + 1) if seen is not None and seen[0] == key else (key, 1)
+            if pa.graph_seen[1] >= 3 and getattr(pa, "fv_jobs", None) is not None and pa.h is not None and pa.h.shape[0] == obs.shape[0]:
+                n = obs.shape[0]
+                packed = obs.dtype == torch.int32
+                fn = K.lib().hb_actor_hidden_packed if packed else K.lib().hb_actor_hidden
+                qbuf = torch.empty(n, self.n_actions, dtype=torch.float32, device=self.device)
+
+                def forward():
+                    st = K.current_stream()
+                    K.check(K.lib().hb_actor_pack_weights(pa.fv_jobs, 1, st))
+                    pa.w2f.copy_(fv.w2st[0][:, 0:2 * self.n_actions:2])
+                    pa.b2f.copy_(fv.b2st[0][0:2 * self.n_actions:2])
+                    K.check(fn(K.dptr(obs), n, self.obs_len, K.dptr(pa.w1t), kp, K.dptr(pa.b1), hidden, K.dptr(pa.h), st))
+                    torch.addmm(pa.b2f, pa.h.float(), pa.w2f, out=qbuf)
+
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    forward()
+                pa.graph = (key, g, qbuf)
+                g.replay()
+                pa.stale, self._eff_cache = False, True
+                return self._plain_select(qbuf, legal, epsilon, n)
         if (pa.stale or self._eff_cache is None) and fv is not None and fv.cd == torch.bfloat16:
             # the learner keeps bf16 copies of the online weights current: transpose W1 from there (one launch, cached job
             # table) and refresh the fp32 image of the bf16 output layer (two strided copies) — no allocation, no casts
             if getattr(pa, "fv_jobs", None) is None:
+                pa.graph = pa.graph_seen = None   # (a captured forward holds the old buffers)
                 pa.w2f = torch.empty(hidden, self.n_actions, dtype=torch.float32, device=self.device)
                 pa.b2f = torch.empty(self.n_actions, dtype=torch.float32, device=self.device)
                 jobs = (K.HbPackJob * 1)()
@@ -300,6 +338,7 @@ class DQNAgent:
             self._eff_cache = True
         if pa.stale or self._eff_cache is None:
             pa.fv_jobs = None   # (this path re-creates w2f / b2f)
+            pa.graph = pa.graph_seen = None
             w1, w2 = self.online.weights[0].detach(), self.online.weights[1].detach()
             b1, b2 = self.online.biases[0].detach(), self.online.biases[1].detach()
             w1p = torch.zeros(kp, hidden, dtype=torch.bfloat16, device=self.device)
@@ -321,6 +360,12 @@ class DQNAgent:
         fn = L.hb_actor_hidden_packed if packed else L.hb_actor_hidden
         K.check(fn(K.dptr(obs.contiguous()), n, self.obs_len, K.dptr(pa.w1t), kp, K.dptr(pa.b1), hidden, K.dptr(pa.h), s))
         q = torch.addmm(pa.b2f, pa.h.float(), pa.w2f)                      # [N, A] fp32: a tiny GEMM
+        return self._plain_select(q, legal, epsilon, n)
+
+    def _plain_select(self, q, legal, epsilon, n):
+        from hanabi_hip import _capi as K
+
+        L, s = K.lib(), K.current_stream()
         actions = torch.empty(n, dtype=torch.int32, device=self.device)
         self._draws += 1
         K.check(L.hb_policy_select(K.dptr(q), K.dptr(legal.to(torch.int8).contiguous()), n, self.n_actions, float(epsilon),

@@ -769,6 +769,51 @@ def test_vanilla_fast_actor_matches_torch_policy():
     assert bool(legal.gather(1, a8.long()[:, None]).all())
 
 
+def test_vanilla_actor_graph_replay_equals_eager_calls(monkeypatch):
+    """Config 2's acting forward as ONE HIP graph (weight refresh from the learner's bf16 operands, hidden-layer kernel, cast, output
+    GEMM: DQNAgent._act_plain, captured once the same observation buffer has been seen three times) against the same launches made
+    one by one: identical q values and moves, before and after further updates."""
+    import torch
+
+    from hanabi_agents.rlax_dqn import ActionSpec, DQNAgent, ObservationSpec, RlaxRainbowParams, bitpack
+
+    n, obs_len, n_act = 4096, 658, 20
+    params = RlaxRainbowParams(distributional=False, use_priority=False, experience_buffer_size=n, train_batch_size=256,
+                               compute_dtype="bfloat16", epsilon=0.0, learning_rate=0.01, packed_obs=True)
+    agent = DQNAgent(ObservationSpec((n, obs_len)), ActionSpec(n_act), params, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(6)
+    o1 = bitpack.pack((torch.rand(n, obs_len, device="cuda", generator=g) < 0.3).to(torch.int8))
+    o2 = bitpack.pack((torch.rand(n, obs_len, device="cuda", generator=g) < 0.3).to(torch.int8))
+    legal = (torch.rand(n, n_act, device="cuda", generator=g) < 0.6).to(torch.int8)
+    legal[:, 1] = 1
+    act = torch.randint(0, n_act, (n,), device="cuda", generator=g, dtype=torch.int32)
+    agent.add_experience_first((None, (o1, legal)), torch.zeros(n, dtype=torch.int8, device="cuda"))
+    agent.add_experience((None, (o2, legal)), act, torch.ones(n, device="cuda"), torch.ones(n, dtype=torch.int8, device="cuda"))
+    for _ in range(3):
+        agent.update()
+    assert agent._fv is not None and agent._plain_fast
+
+    def call():
+        agent._draws = 7
+        a = agent.exploit((None, (o1, legal))).clone()
+        return a, agent._last_q.clone()
+
+    for _ in range(4):
+        a_g, q_g = call()
+    assert agent._plain_actor.graph is not None, "the forward must have been captured by now"
+    monkeypatch.setenv("HB_PLAIN_ACT_GRAPH", "0")
+    a_e, q_e = call()
+    assert torch.equal(q_g, q_e) and torch.equal(a_g, a_e)
+    monkeypatch.setenv("HB_PLAIN_ACT_GRAPH", "1")
+    for _ in range(2):
+        agent.update()
+    a_g, q_g = call()              # replayed: must see the new weights
+    monkeypatch.setenv("HB_PLAIN_ACT_GRAPH", "0")
+    a_e2, q_e2 = call()
+    assert torch.equal(q_g, q_e2) and torch.equal(a_g, a_e2)
+    assert not torch.equal(q_e, q_e2)
+
+
 @pytest.mark.parametrize("n,A,atoms,hidden", [(32768, 20, 51, 512), (1000, 20, 51, 512), (300, 48, 51, 512), (700, 11, 21, 256),
                                               (65, 6, 64, 256)])
 def test_selection_fused_into_the_q_gemm_equals_the_separate_launch(n, A, atoms, hidden):
