@@ -69,7 +69,7 @@ class SelfPlaySession:
         #  only has to finish before that agent acts again, and two 0.14 ms updates on ONE stream outlast two steps)
         self._stream_per_agent = True if stream_per_agent is None else bool(stream_per_agent)
         self._lstreams = {}
-        self.max_learner_streams = 2
+        self.max_learner_streams = int(os.environ.get("HB_MAX_LEARNER_STREAMS", "2"))   # (the variable: measurements)
         if self.learner_stream is not None and split_update:
             for a in agents:
                 if hasattr(a, "set_split_update"):
