@@ -615,7 +615,7 @@ __device__ __forceinline__ tg_f32x4 tg_mfma(const uint4& wv, const uint4& xv, co
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.f, x.f, c, 0, 0, 0);
   }
 }
-template <bool F16>
+template <bool F16, bool PIPE>
 __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const int batch) {
   // One wavefront per (row tile, column tile); it walks the batch itself, so a launch never has more workgroups than
   // (m / 32) * (n / 16): for the learner's shapes that is 1 024 = one wavefront per SIMD of the chip, which leaves an
@@ -635,12 +635,34 @@ __global__ __launch_bounds__(64) void thin_gemm_kernel(const ThinArgs a, const i
     const unsigned xo = (z * a.x_bs + (blockIdx.x * 32u + lr) * a.ldx + kq * 8u) * 2u;
     const unsigned wo = (z * a.w_bs + (ct * 16u + lr) * a.ldw + kq * 8u) * 2u;
     tg_f32x4 acc0 = tg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    // PIPE (HB_THIN_PIPE=1, measurements only): the operands of K step s + 1 requested before the MFMAs of step s — one wavefront per
+    // SIMD has nobody to hide its load latency behind. 12 more registers (48: the most that fits beside an actor workgroup).
+    // Measured round 3, same box, alternating: the kernel gains 6 % (14.2 vs 15.1 us in the loop) and the STEP loses 15 % (0.128 vs
+    // 0.112 ms): at 48 registers it takes everything an actor workgroup leaves, and the learner's other small kernels (36-47
+    // registers) no longer share a SIMD with it. The plain loop (36 registers) is what runs.
+    const unsigned kend = static_cast<unsigned>(a.k) * 2u;
+    if constexpr (PIPE) {
+      uint4 x0 = *reinterpret_cast<const uint4*>(a.x + xo), x1 = *reinterpret_cast<const uint4*>(a.x + xo + half);
+      uint4 w0 = *reinterpret_cast<const uint4*>(a.wt + wo);
 #pragma unroll 1
-    for (unsigned kb = 0; kb < static_cast<unsigned>(a.k) * 2u; kb += 64u) {
-      const uint4 x0 = *reinterpret_cast<const uint4*>(a.x + xo + kb), x1 = *reinterpret_cast<const uint4*>(a.x + xo + kb + half);
-      const uint4 w0 = *reinterpret_cast<const uint4*>(a.wt + wo + kb);
+      for (unsigned kb = 64u; kb < kend; kb += 64u) {
+        const uint4 nx0 = *reinterpret_cast<const uint4*>(a.x + xo + kb), nx1 = *reinterpret_cast<const uint4*>(a.x + xo + kb + half);
+        const uint4 nw0 = *reinterpret_cast<const uint4*>(a.wt + wo + kb);
+        asm volatile("" ::: "memory");   // (the loads are issued here, not sunk below the MFMAs)
+        acc0 = tg_mfma<F16>(w0, x0, acc0);
+        acc1 = tg_mfma<F16>(w0, x1, acc1);
+        x0 = nx0; x1 = nx1; w0 = nw0;
+      }
       acc0 = tg_mfma<F16>(w0, x0, acc0);
       acc1 = tg_mfma<F16>(w0, x1, acc1);
+    } else {
+#pragma unroll 1
+      for (unsigned kb = 0; kb < kend; kb += 64u) {
+        const uint4 x0 = *reinterpret_cast<const uint4*>(a.x + xo + kb), x1 = *reinterpret_cast<const uint4*>(a.x + xo + kb + half);
+        const uint4 w0 = *reinterpret_cast<const uint4*>(a.wt + wo + kb);
+        acc0 = tg_mfma<F16>(w0, x0, acc0);
+        acc1 = tg_mfma<F16>(w0, x1, acc1);
+      }
     }
     // acc_m[j] = out[row 32 bx + 16 m + (lane & 15)][col 16 by + 4 (lane >> 4) + j]
     float v[8] = {acc0[0] + b0, acc0[1] + b1, acc0[2] + b2, acc0[3] + b3, acc1[0] + b0, acc1[1] + b1, acc1[2] + b2, acc1[3] + b3};
@@ -714,12 +736,18 @@ int hb_thin_gemm(const void* x_dev, const void* wt_dev, const void* bias_dev, vo
              static_cast<unsigned>(w_batch_stride), static_cast<unsigned>(out_batch_stride), k, relu, 0u, static_cast<unsigned>(n)};
   // at most 1 024 workgroups (= wavefronts) per launch: one per SIMD of the chip, so that an actor-GEMM workgroup arriving
   // while this kernel runs still finds its registers; wider outputs take several launches
+  const bool pipe = [] { const char* e = getenv("HB_THIN_PIPE"); return e && e[0] == '1'; }();
   const unsigned tiles = static_cast<unsigned>(n / 16), gx = static_cast<unsigned>(m / 32), cap = gx >= 1024u ? 1u : 1024u / gx;
   for (unsigned t0 = 0; t0 < tiles; t0 += cap) {
     a.n_tiles = t0;
     const dim3 grid(gx, tiles - t0 < cap ? tiles - t0 : cap);
-    if (relu & 4) hipLaunchKernelGGL(thin_gemm_kernel<true>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
-    else hipLaunchKernelGGL(thin_gemm_kernel<false>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+    if (pipe) {
+      if (relu & 4) hipLaunchKernelGGL((thin_gemm_kernel<true, true>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+      else hipLaunchKernelGGL((thin_gemm_kernel<false, true>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+    } else {
+      if (relu & 4) hipLaunchKernelGGL((thin_gemm_kernel<true, false>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+      else hipLaunchKernelGGL((thin_gemm_kernel<false, false>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, batch);
+    }
   }
   HB_HIP(hipGetLastError());
   return HB_OK;
