@@ -62,9 +62,8 @@ class SelfPlaySession:
         self._dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         # one learner stream per agent: seat A's update (launched at step t, needed at t + P) runs beside seat B's (t + 1):
         # the two latency-bound kernel chains interleave instead of queueing one behind the other
-        # (default: data-parallel runs, and asynchronous actors — there the acting stream waits for the seat's own `gathered`
+        # (rounds 1-2: only data-parallel runs and asynchronous actors — there the acting stream waits for the seat's own `gathered`
         # event only, which on a shared learner stream would sit behind the OTHER seat's whole update: 0.137 vs 0.150 ms per step)
-        lagging = any(getattr(a, "actor_lag", 0) for a in agents)
         # (round 3: also the plain synchronous agents — config 2's vanilla DQN went 0.163 -> 0.139 ms per step: each agent's update
         #  only has to finish before that agent acts again, and two 0.14 ms updates on ONE stream outlast two steps)
         self._stream_per_agent = True if stream_per_agent is None else bool(stream_per_agent)
