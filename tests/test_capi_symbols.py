@@ -110,6 +110,24 @@ def test_argument_validation_needs_no_gpu():
     tab = (K.HbAdamTensor * 1)()
     assert L.hb_noisy_adam_multi(tab, 1, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0 and b"tensor 0" in L.hb_last_error()
     assert L.hb_noisy_adam_multi(tab, 9, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0
+    # round 3: the packing Adam, the one-kernel actor's entry points and the chain
+    packs = (K.HbAdamPack * 1)()
+    assert L.hb_noisy_adam_multi_pack(tab, packs, 1, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0 and b"tensor 0" in L.hb_last_error()
+    assert L.hb_noisy_adam_multi_pack(tab, packs, 5, one, 1.0, 1, 1e-3, 0.9, 0.999, 1e-5, None) < 0
+    assert L.hb_noisy_adam_multi_pack(tab, packs, 1, one, 1.0, 0, 1e-3, 0.9, 0.999, 1e-5, None) < 0 and b"16-bit" in L.hb_last_error()
+    cols = (C.c_int32 * (20 * 51))()
+    assert L.hb_actor_fused_columns(20, cols) == 0 and sorted(cols) == sorted(set(cols)) and max(cols) < 1024 and min(cols) >= 0
+    assert L.hb_actor_fused_columns(81, cols) < 0
+    assert L.hb_actor_fused_supported(658, 512, 20, 51) == 1 and L.hb_actor_fused_supported(658, 512, 81, 51) == 0
+    assert L.hb_actor_fused_q_dt(one, 10, 658, one, one, one, one, one, 512, 20, 51, one, 3, None) < 0 and b"dtype" in L.hb_last_error()
+    assert L.hb_actor_fused_act_dt(one, None, 10, 658, one, one, one, one, one, 512, 20, 51, one, 0.1, 1, 1, 0, one, 1, None) < 0
+    assert L.hb_actor_fused_pack_thin(one, 512, one, one, 1024, one, 658, 512, 20, 51, one, one, one, one, one, 100, None, 0, 1, None) < 0
+    assert b"w1t" in L.hb_last_error()
+    assert L.hb_thin_gemm(one, one, None, one, 32, 16, 32, 32, 32, 16, 1, 0, 0, 0, 8, None) < 0 and b"relu" in L.hb_last_error()
+    cmds = (K.HbCmd * 1)()
+    cmds[0].op, cmds[0].var, cmds[0].fvar, cmds[0].cond = 99, -1, -1, -1
+    assert L.hb_chain_run(cmds, 1, None, None) < 0 and b"unknown op" in L.hb_last_error()
+    assert L.hb_chain_run(cmds, 0, None, None) == 0
     assert L.hb_per_sample_philox(None, 1, one, 4, one, one, None) < 0
     assert L.hb_tree_import_nodes(None, one, None) < 0
     assert L.hb_env_state(None) is None
