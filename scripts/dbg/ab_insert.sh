@@ -1,3 +1,5 @@
+# NOTE: HB_INSERT_ON_LEARNER was a temporary switch in hanabi_hip/selfplay.py (the replay insert on the learner stream inside the
+# hb_chain_run command list); measured, not kept, the switch is no longer in the tree: results in profiles/r03/ab_update_tail.txt.
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r03q; mkdir -p $O
 run() {
   label=$1; shift

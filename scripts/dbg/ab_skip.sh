@@ -1,3 +1,5 @@
+# NOTE: HB_DBG_SKIP was a temporary, timing-only switch in rlax_dqn/fused_learner.py (tail kernels left out of the captured update:
+# results are wrong by construction); it is no longer in the tree: results in profiles/r03/ab_update_tail.txt.
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/r03q; mkdir -p $O
 run() {
   label=$1; shift
