@@ -570,22 +570,22 @@ def main():
     if (session is not None and not args.vanilla and args.actor_lag == 0 and args.compute_dtype in ("bfloat16", "float16")
             and not args.no_async_variant and env.packed):
         session.flush()
-        line["async_actor"] = async_variant(args, rank, world, device, n,   # (every rank: it holds collectives)
-                                            streams=list(dict.fromkeys(session._lstreams.values())))
+        line["async_actor"] = _variant(async_variant, args, rank, world, device, n,   # (every rank: it holds collectives)
+                                       streams=list(dict.fromkeys(session._lstreams.values())))
     if (session is not None and not args.vanilla and args.actor_lag == 0 and args.n_step == 1 and not args.no_nstep_variant
             and env.packed and args.compute_dtype in ("bfloat16", "float16")):
         # north_star: "n-step double-DQN loss". The reference's rlax agent is 1-step (the headline); the n-step form it describes
         # (replay_memory.py:316-345) is timed beside it
         session.flush()
-        line["n_step_3"] = async_variant(args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
-                                         actor_lag=0, n_step=3)
+        line["n_step_3"] = _variant(async_variant, args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
+                                    actor_lag=0, n_step=3)
     if (session is not None and not args.vanilla and args.actor_lag == 0 and args.n_step == 1 and not args.no_fp16_variant
             and env.packed and args.compute_dtype == "bfloat16"):
         # the reference's own network dtype (rlax_rainbow.py:250-251: fp16) on the same kernels (v_mfma_f32_16x16x32_f16: the same
         # MFMA rate; 8 x finer operand rounding: tolerance.py's float16 row instead of the bfloat16 one)
         session.flush()
-        line["fp16_operands"] = async_variant(args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
-                                              actor_lag=0, n_step=1, dtype="float16")
+        line["fp16_operands"] = _variant(async_variant, args, rank, world, device, n, streams=list(dict.fromkeys(session._lstreams.values())),
+                                         actor_lag=0, n_step=1, dtype="float16")
     if rank == 0 and not args.no_cpu_baseline:
         note = lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)   # progress on stderr; stdout carries the ONE JSON line
         note(f"timed region done ({dt / args.steps * 1e3:.4f} ms per step); timing the CPU baselines on rank 0")
@@ -615,6 +615,18 @@ def main():
         dist.barrier()
     if world > 1 or force_coll:
         dist.destroy_process_group()
+
+
+def _variant(fn, *a, **kw):
+    """A side measurement must never cost the headline its JSON line: single rank, a failure is reported in the variant's place.
+    (Data-parallel runs re-raise: the other ranks are inside the variant's collectives and would hang.)"""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:   # noqa: BLE001
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise
+        print(f"[bench] variant failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def async_variant(args, rank, world, device, n, streams=None, actor_lag=1, n_step=None, dtype=None):
