@@ -24,6 +24,14 @@ def _has_gpu():
 
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
+        # A GPU test takes seconds (the whole -m gpu suite ~95 s, plus 1-2 min of first `import torch` on a cold box). One that runs
+        # for minutes is stuck — a stream waiting for an event nobody records, a kernel that does not drain: with pytest-timeout
+        # (in this image) it then fails with the Python stacks of all threads in the log and the process EXITS, instead of
+        # sitting silent until the box's watchdog kills the run.
+        if config.pluginmanager.hasplugin("timeout"):
+            for item in items:
+                if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                    item.add_marker(pytest.mark.timeout(300, method="thread"))
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
